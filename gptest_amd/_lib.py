@@ -1,0 +1,143 @@
+"""ctypes binding of libgpk.so (the C-ABI declared in include/gpk.h).
+
+The product path fails loudly: no NumPy/CPU fallback exists anywhere in this
+package.  ``lib()`` raises ``GpkError`` when the shared library is not built and
+``init()`` raises when no gfx950 device is visible.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgpk.so")
+_lib = None
+_inited = False
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+
+class GpkError(RuntimeError):
+    """API / HIP / RCCL failure inside libgpk.so (negative return code)."""
+
+
+def _bind(l):
+    i, d, vp, cp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_char_p
+    dp = c_double_p
+    sig = {
+        "gpk_abi_version": (i, []),
+        "gpk_device_count": (i, []),
+        "gpk_init": (i, [i]),
+        "gpk_shutdown": (None, []),
+        "gpk_last_error": (cp, []),
+        "gpk_sync": (i, []),
+        "gpk_set_option": (i, [cp, d]),
+        "gpk_get_option": (d, [cp]),
+        "gpk_comm_unique_id": (i, [vp]),
+        "gpk_comm_init": (i, [i, i, vp]),
+        "gpk_comm_rank": (i, []),
+        "gpk_comm_size": (i, []),
+        "gpk_comm_barrier": (i, []),
+        "gpk_comm_allreduce_max": (i, [dp, i]),
+        "gpk_comm_destroy": (i, []),
+        "gpk_sqdist": (i, [dp, i, dp, i, i, dp]),
+        "gpk_se_kxx": (i, [dp, i, i, dp, d, dp]),
+        "gpk_se_kxz": (i, [dp, i, dp, i, i, dp, dp]),
+        "gpk_potrf": (i, [dp, i]),
+        "gpk_fit": (i, [dp, dp, i, i, dp, d, i, c_void_pp, dp]),
+        "gpk_predict": (i, [vp, dp, i, dp, dp]),
+        "gpk_solve": (i, [vp, dp, i, dp]),
+        "gpk_solve_lower": (i, [vp, dp, i, dp]),
+        "gpk_kmatvec": (i, [vp, dp, i, dp]),
+        "gpk_kgather": (i, [vp, ctypes.POINTER(ctypes.c_longlong), i, dp]),
+        "gpk_model_scalar": (i, [vp, i, dp]),
+        "gpk_model_get_L": (i, [vp, dp]),
+        "gpk_free": (i, [vp]),
+        "gpk_last_timing": (i, [cp, dp, dp]),
+        "gpk_bench_posterior": (i, [dp, dp, i, i, dp, dp, i, i, i, dp, dp, dp, dp]),
+        "gpk_test_gemm_nt": (i, [dp, dp, dp, i, i, i, i, i, i]),
+        "gpk_test_potf2_128": (i, [dp, dp, dp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(l, name)  # AttributeError here = header/library mismatch
+        f.restype = res
+        f.argtypes = args
+    return sig
+
+
+EXPORTS = None
+
+
+def lib():
+    """Load libgpk.so (once).  Raises GpkError if it has not been built."""
+    global _lib, EXPORTS
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise GpkError(
+                "libgpk.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C gptest_amd/csrc`. There is no CPU fallback." % _LIB_PATH
+            )
+        l = ctypes.CDLL(_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        EXPORTS = _bind(l)
+        if l.gpk_abi_version() != 1:
+            raise GpkError("libgpk.so ABI version %d, expected 1" % l.gpk_abi_version())
+        _lib = l
+    return _lib
+
+
+def last_error():
+    return lib().gpk_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    """rc < 0 -> GpkError; rc > 0 -> numpy.linalg.LinAlgError (what GPpref.py:133 catches)."""
+    if rc == 0:
+        return
+    if rc > 0:
+        raise np.linalg.LinAlgError("%s: %s" % (what, last_error() or "Matrix is not positive definite"))
+    raise GpkError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+def init(device=None):
+    """Bind this process to one GPU (LOCAL_RANK by default).  Idempotent."""
+    global _inited
+    l = lib()
+    if _inited:
+        return
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    n = l.gpk_device_count()
+    if n <= 0:
+        raise GpkError("no HIP device visible: the gptest_amd product path needs an MI355X (gfx950); "
+                       "there is no CPU fallback")
+    check(l.gpk_init(int(device) % n), "gpk_init")
+    _inited = True
+
+
+def shutdown():
+    global _inited
+    if _lib is not None and _inited:
+        _lib.gpk_shutdown()
+    _inited = False
+
+
+def set_option(key, value):
+    init()
+    check(lib().gpk_set_option(key.encode(), float(value)), "gpk_set_option(%s)" % key)
+
+
+def get_option(key):
+    init()
+    return lib().gpk_get_option(key.encode())
+
+
+def as_c(a):
+    """C-contiguous float64 view/copy + its ctypes pointer (inputs are never mutated)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(c_double_p)
+
+
+def out_array(shape):
+    a = np.empty(shape, dtype=np.float64)
+    return a, a.ctypes.data_as(c_double_p)

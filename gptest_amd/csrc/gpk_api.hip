@@ -1,0 +1,493 @@
+// extern "C" surface of libgpk.so (see include/gpk.h for the contract and the
+// reference file:line each entry point replaces).
+#include "../../include/gpk.h"
+#include "gpk_core.h"
+#include <cmath>
+
+const char* gpk_err_cstr();
+
+extern "C" {
+
+int gpk_abi_version(void) { return GPK_ABI_VERSION; }
+
+int gpk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int gpk_init(int device) {
+  if (G.inited) {
+    if (device == G.device) return 0;
+    return gpk_set_err(-1, "gpk_init: already bound to device %d", G.device);
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return gpk_set_err(-2, "gpk_init: no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return gpk_set_err(-1, "gpk_init: device %d outside 0..%d", device, n - 1);
+  GPK_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  GPK_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return gpk_set_err(-2, "gpk_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                       prop.gcnArchName);
+  int lo = 0, hi = 0;
+  GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  GPK_HIP(hipStreamCreateWithPriority(&G.s_main, hipStreamNonBlocking, lo));
+  GPK_HIP(hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, hi));
+  GPK_HIP(hipStreamCreateWithPriority(&G.s_comm, hipStreamNonBlocking, hi));
+  G.device = device;
+  G.inited = true;
+  return 0;
+}
+
+void gpk_shutdown(void) {
+  if (!G.inited) return;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : G.pool)
+    for (void* q : kv.second) (void)hipFree(q);
+  G.pool.clear();
+  G.pool_bytes = 0;
+  timers_reset();
+  for (hipEvent_t e : G.ev_free) (void)hipEventDestroy(e);
+  G.ev_free.clear();
+  if (G.s_main) (void)hipStreamDestroy(G.s_main);
+  if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
+  if (G.s_comm) (void)hipStreamDestroy(G.s_comm);
+  G.s_main = G.s_panel = G.s_comm = nullptr;
+  G.inited = false;
+}
+
+const char* gpk_last_error(void) { return gpk_err_cstr(); }
+
+int gpk_sync(void) {
+  GPK_TRY(rt_require());
+  GPK_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+int gpk_set_option(const char* key, double value) {
+  std::string k(key ? key : "");
+  if (k == "nb") {
+    int nb = (int)value;
+    if (nb < 128 || nb % 128) return gpk_set_err(-1, "option nb=%d must be a positive multiple of 128", nb);
+    G.nb = nb;
+  } else if (k == "lookahead") {
+    G.lookahead = (int)value;
+  } else if (k == "timing") {
+    G.timing = (int)value;
+    if (!G.timing) timers_reset();
+  } else {
+    return gpk_set_err(-1, "unknown option '%s'", k.c_str());
+  }
+  return 0;
+}
+double gpk_get_option(const char* key) {
+  std::string k(key ? key : "");
+  if (k == "nb") return G.nb;
+  if (k == "lookahead") return G.lookahead;
+  if (k == "timing") return G.timing;
+  if (k == "pool_bytes") return (double)G.pool_bytes;
+  return NAN;
+}
+
+// ---------------------------------------------------------------- builders
+static int se_build_host(const double* Rh, int nr, const double* Ch, int nc, int d, const SEParams& se, int same,
+                         int mode, double* out_h) {
+  GPK_TRY(rt_require());
+  if (nr < 1 || nc < 1) return gpk_set_err(-1, "empty input (%d x %d)", nr, nc);
+  hipStream_t s = G.s_main;
+  const int nrp = round_up(nr, 128), ncp = round_up(nc, 128);
+  double *dR = nullptr, *dC = nullptr, *dO = nullptr;
+  GPK_TRY(dev_alloc_t(&dR, (size_t)nr * d));
+  if (!same) GPK_TRY(dev_alloc_t(&dC, (size_t)nc * d));
+  GPK_TRY(dev_alloc_t(&dO, (size_t)nrp * ncp));
+  int rc = 0;
+  do {
+    if (hipMemcpyAsync(dR, Rh, (size_t)nr * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    if (!same && hipMemcpyAsync(dC, Ch, (size_t)nc * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    rc = launch_se_build(dR, nr, nrp, same ? dR : dC, nc, ncp, se, same, mode, dO, ncp, 0, s);
+    if (rc) break;
+    if (hipMemcpy2DAsync(out_h, (size_t)nc * 8, dO, (size_t)ncp * 8, (size_t)nc * 8, nr, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "stream sync failed: %s", hipGetErrorString(hipGetLastError())); break; }
+  } while (0);
+  dev_free(dR, (size_t)nr * d * 8);
+  if (dC) dev_free(dC, (size_t)nc * d * 8);
+  dev_free(dO, (size_t)nrp * ncp * 8);
+  return rc;
+}
+
+int gpk_sqdist(const double* A, int n, const double* B, int m, int d, double* out) {
+  if (!A || !B || !out) return gpk_set_err(-1, "gpk_sqdist: null pointer");
+  if (d < 1 || d > 32) return gpk_set_err(-1, "input dimension d=%d outside 1..32", d);
+  SEParams se{};
+  se.d = d;
+  for (int k = 0; k < d; ++k) se.ell[k] = 1.0;
+  se.sf2 = 1.0;
+  return se_build_host(A, n, B, m, d, se, 0, 1, out);
+}
+
+int gpk_se_kxx(const double* X, int N, int d, const double* log_hyp, double jitter, double* K_out) {
+  if (!X || !log_hyp || !K_out) return gpk_set_err(-1, "gpk_se_kxx: null pointer");
+  if (d < 1 || d > 32) return gpk_set_err(-1, "input dimension d=%d outside 1..32", d);
+  gpk_model tmp;
+  GPK_TRY(decode_hyp(log_hyp, d, jitter, &tmp));
+  return se_build_host(X, N, X, N, d, tmp.se, 1, 0, K_out);
+}
+
+int gpk_se_kxz(const double* X, int N, const double* Z, int M, int d, const double* log_hyp, double* Kxz_out) {
+  if (!X || !Z || !log_hyp || !Kxz_out) return gpk_set_err(-1, "gpk_se_kxz: null pointer");
+  if (d < 1 || d > 32) return gpk_set_err(-1, "input dimension d=%d outside 1..32", d);
+  gpk_model tmp;
+  GPK_TRY(decode_hyp(log_hyp, d, 0.0, &tmp));
+  return se_build_host(X, N, Z, M, d, tmp.se, 0, 0, Kxz_out);
+}
+
+// ---------------------------------------------------------------- potrf on a caller matrix
+__global__ void pad_identity_kernel(double* K, long ld, int N, int Npad) {
+  // zero the padding rows/cols and put 1 on the padded diagonal
+  const long total = (long)Npad * Npad;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(e / Npad), j = (int)(e % Npad);
+    if (i >= N || j >= N) K[(long)i * ld + j] = (i == j) ? 1.0 : 0.0;
+  }
+}
+
+static int model_unpack_L(gpk_model* m, double* L_out_host) {
+  hipStream_t s = G.s_main;
+  const int N = m->N;
+  double* dOut = nullptr;
+  GPK_TRY(dev_alloc_t(&dOut, (size_t)N * N));
+  int rc = 0;
+  for (int p = 0; p < m->nP && !rc; ++p)
+    rc = launch_unpack_L(m->Lpanel(p), m->pw[p], m->Npad - m->pc0[p], m->pc0[p], dOut, N, s);
+  if (!rc && hipMemcpyAsync(L_out_host, dOut, (size_t)N * N * 8, hipMemcpyDeviceToHost, s) != hipSuccess) rc = gpk_set_err(-2, "D2H failed");
+  if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = gpk_set_err(-2, "stream sync failed");
+  dev_free(dOut, (size_t)N * N * 8);
+  return rc;
+}
+
+int gpk_potrf(double* A, int N) {
+  if (!A) return gpk_set_err(-1, "gpk_potrf: null pointer");
+  gpk_model* m = nullptr;
+  GPK_TRY(model_create(&m, N, 1, false));
+  hipStream_t s = G.s_main;
+  int rc = 0;
+  do {
+    if (hipMemcpy2DAsync(m->dK, (size_t)m->Npad * 8, A, (size_t)N * 8, (size_t)N * 8, N, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    if (m->Npad != N) hipLaunchKernelGGL(pad_identity_kernel, dim3(1024), dim3(256), 0, s, m->dK, (long)m->Npad, N, m->Npad);
+    rc = potrf_device(m);
+    if (rc) break;
+    int hinfo = 0;
+    if (hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "potrf: %s", hipGetErrorString(hipGetLastError())); break; }
+    if (hinfo > 0) { rc = hinfo > N ? N : hinfo; gpk_set_err(rc, "matrix is not positive definite (leading minor %d)", rc); break; }
+    rc = model_unpack_L(m, A);
+  } while (0);
+  model_destroy(m);
+  return rc;
+}
+
+// ---------------------------------------------------------------- fused model entry points
+int gpk_fit(const double* X, const double* y, int N, int d, const double* log_hyp, double jitter, int flags,
+            gpk_model** handle_out, double* nlml_out) {
+  if (!X || !log_hyp || !handle_out) return gpk_set_err(-1, "gpk_fit: null pointer");
+  *handle_out = nullptr;
+  gpk_model* m = nullptr;
+  GPK_TRY(model_create(&m, N, d, (flags & 1) != 0));
+  hipStream_t s = G.s_main;
+  int rc = decode_hyp(log_hyp, d, jitter, m);
+  if (!rc && hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
+  m->has_y = (y != nullptr);
+  if (!rc && y) {
+    if (hipMemsetAsync(m->dy, 0, (size_t)m->Npad * 8, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
+    if (!rc && hipMemcpyAsync(m->dy, y, (size_t)N * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
+  }
+  if (!rc) rc = fit_device(m);
+  if (rc) {
+    if (rc > 0) gpk_set_err(rc, "kernel matrix is not positive definite (leading minor %d)", rc);
+    model_destroy(m);
+    return rc;
+  }
+  if (nlml_out) *nlml_out = m->nlml;
+  *handle_out = m;
+  return 0;
+}
+
+int gpk_predict(gpk_model* m, const double* Z, int M, double* mean_out, double* var_out) {
+  GPK_TRY(rt_require());
+  if (!m || !Z || !mean_out || !var_out) return gpk_set_err(-1, "gpk_predict: null pointer");
+  if (!m->has_y) return gpk_set_err(-1, "gpk_predict: model was fitted without targets");
+  if (M < 1) return gpk_set_err(-1, "gpk_predict: M=%d must be >= 1", M);
+  hipStream_t s = G.s_main;
+  const int Mpad = round_up(M, 128);
+  double *dZ = nullptr, *dR = nullptr, *dV = nullptr, *dmv = nullptr;
+  const size_t szR = (size_t)Mpad * m->Npad;
+  int rc = 0;
+  rc |= dev_alloc_t(&dZ, (size_t)M * m->d);
+  rc |= dev_alloc_t(&dR, szR);
+  rc |= dev_alloc_t(&dV, szR);
+  rc |= dev_alloc_t(&dmv, (size_t)2 * Mpad);
+  if (!rc) {
+    do {
+      if (hipMemcpyAsync(dZ, Z, (size_t)M * m->d * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+      rc = predict_device(m, dZ, M, Mpad, dR, dV, dmv, dmv + Mpad);
+      if (rc) break;
+      if (hipMemcpyAsync(mean_out, dmv, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+      if (hipMemcpyAsync(var_out, dmv + Mpad, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+      if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "predict: %s", hipGetErrorString(hipGetLastError())); break; }
+    } while (0);
+  }
+  if (dZ) dev_free(dZ, (size_t)M * m->d * 8);
+  if (dR) dev_free(dR, szR * 8);
+  if (dV) dev_free(dV, szR * 8);
+  if (dmv) dev_free(dmv, (size_t)2 * Mpad * 8);
+  return rc;
+}
+
+static int solve_common(gpk_model* m, const double* B, int nrhs, double* X_out, bool backward) {
+  GPK_TRY(rt_require());
+  if (!m || !B || !X_out) return gpk_set_err(-1, "gpk_solve: null pointer");
+  if (nrhs < 1) return gpk_set_err(-1, "gpk_solve: nrhs=%d must be >= 1", nrhs);
+  hipStream_t s = G.s_main;
+  const int N = m->N, np_ = m->Npad;
+  double* dv = nullptr;
+  GPK_TRY(dev_alloc_t(&dv, (size_t)np_));
+  std::vector<double> col(np_, 0.0);
+  int rc = 0;
+  for (int j = 0; j < nrhs && !rc; ++j) {
+    for (int i = 0; i < N; ++i) col[i] = B[(size_t)i * nrhs + j];
+    if (hipMemcpyAsync(dv, col.data(), (size_t)np_ * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    rc = trsv_forward(m, dv);
+    if (!rc && backward) rc = trsv_backward(m, dv);
+    if (rc) break;
+    if (hipMemcpyAsync(col.data(), dv, (size_t)N * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "solve: %s", hipGetErrorString(hipGetLastError())); break; }
+    for (int i = 0; i < N; ++i) X_out[(size_t)i * nrhs + j] = col[i];
+  }
+  dev_free(dv, (size_t)np_ * 8);
+  return rc;
+}
+int gpk_solve(gpk_model* m, const double* B, int nrhs, double* X_out) { return solve_common(m, B, nrhs, X_out, true); }
+int gpk_solve_lower(gpk_model* m, const double* B, int nrhs, double* X_out) { return solve_common(m, B, nrhs, X_out, false); }
+
+int gpk_kmatvec(gpk_model* m, const double* B, int nrhs, double* out) {
+  GPK_TRY(rt_require());
+  if (!m || !B || !out) return gpk_set_err(-1, "gpk_kmatvec: null pointer");
+  if (!m->dKcopy) return gpk_set_err(-1, "gpk_kmatvec: model was fitted without the keep-K flag");
+  hipStream_t s = G.s_main;
+  const int N = m->N, np_ = m->Npad;
+  double *dv = nullptr, *dr = nullptr;
+  GPK_TRY(dev_alloc_t(&dv, (size_t)np_));
+  GPK_TRY(dev_alloc_t(&dr, (size_t)np_));
+  std::vector<double> col(np_, 0.0);
+  int rc = 0;
+  for (int j = 0; j < nrhs && !rc; ++j) {
+    for (int i = 0; i < N; ++i) col[i] = B[(size_t)i * nrhs + j];
+    for (int i = N; i < np_; ++i) col[i] = 0.0;
+    if (hipMemcpyAsync(dv, col.data(), (size_t)np_ * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    rc = launch_gemv(m->dKcopy, np_, np_, np_, dv, dr, 1.0, 0.0, s);
+    if (rc) break;
+    if (hipMemcpyAsync(col.data(), dr, (size_t)N * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "kmatvec: %s", hipGetErrorString(hipGetLastError())); break; }
+    for (int i = 0; i < N; ++i) out[(size_t)i * nrhs + j] = col[i];
+  }
+  dev_free(dv, (size_t)np_ * 8);
+  dev_free(dr, (size_t)np_ * 8);
+  return rc;
+}
+
+int gpk_kgather(gpk_model* m, const long long* idx, int nidx, double* out) {
+  GPK_TRY(rt_require());
+  if (!m || !idx || !out) return gpk_set_err(-1, "gpk_kgather: null pointer");
+  if (!m->dKcopy) return gpk_set_err(-1, "gpk_kgather: model was fitted without the keep-K flag");
+  for (int i = 0; i < nidx; ++i)
+    if (idx[i] < 0 || idx[i] >= m->N) return gpk_set_err(-1, "gpk_kgather: index %lld outside 0..%d", idx[i], m->N - 1);
+  hipStream_t s = G.s_main;
+  long long* didx = nullptr;
+  double* dout = nullptr;
+  GPK_TRY(dev_alloc_t(&didx, (size_t)nidx));
+  GPK_TRY(dev_alloc_t(&dout, (size_t)nidx * nidx));
+  int rc = 0;
+  do {
+    if (hipMemcpyAsync(didx, idx, (size_t)nidx * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    rc = launch_gather2d(m->dKcopy, m->Npad, didx, nidx, dout, s);
+    if (rc) break;
+    if (hipMemcpyAsync(out, dout, (size_t)nidx * nidx * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "kgather: %s", hipGetErrorString(hipGetLastError())); break; }
+  } while (0);
+  dev_free(didx, (size_t)nidx * 8);
+  dev_free(dout, (size_t)nidx * nidx * 8);
+  return rc;
+}
+
+int gpk_model_scalar(gpk_model* m, int which, double* out) {
+  if (!m || !out) return gpk_set_err(-1, "gpk_model_scalar: null pointer");
+  switch (which) {
+    case 0: *out = m->nlml; break;
+    case 1: *out = m->logdet; break;
+    case 2: *out = m->quad; break;
+    case 3: *out = m->se.sf2; break;
+    case 4: *out = m->sn2; break;
+    default: return gpk_set_err(-1, "gpk_model_scalar: unknown selector %d", which);
+  }
+  return 0;
+}
+
+int gpk_model_get_L(gpk_model* m, double* L_out) {
+  GPK_TRY(rt_require());
+  if (!m || !L_out) return gpk_set_err(-1, "gpk_model_get_L: null pointer");
+  return model_unpack_L(m, L_out);
+}
+
+int gpk_free(gpk_model* m) {
+  if (!m) return 0;
+  if (G.inited) (void)hipStreamSynchronize(G.s_main);
+  model_destroy(m);
+  return 0;
+}
+
+// ---------------------------------------------------------------- measurement hooks
+int gpk_last_timing(const char* stage, double* ms_out, double* count_out) {
+  GPK_TRY(rt_require());
+  GPK_TRY(timers_resolve());
+  auto it = G.timers.find(stage ? stage : "");
+  if (it == G.timers.end()) {
+    if (ms_out) *ms_out = 0;
+    if (count_out) *count_out = 0;
+    return 0;
+  }
+  if (ms_out) *ms_out = it->second.ms;
+  if (count_out) *count_out = it->second.count;
+  return 0;
+}
+
+int gpk_bench_posterior(const double* X, const double* y, int N, int d, const double* log_hyp, const double* Z, int M,
+                        int warmup, int reps, double* ms_total_out, double* nlml_out, double* mean_out,
+                        double* var_out) {
+  GPK_TRY(rt_require());
+  if (!X || !y || !log_hyp || !Z) return gpk_set_err(-1, "gpk_bench_posterior: null pointer");
+  gpk_model* m = nullptr;
+  GPK_TRY(model_create(&m, N, d, false));
+  hipStream_t s = G.s_main;
+  const int Mpad = round_up(M, 128);
+  const size_t szR = (size_t)Mpad * m->Npad;
+  double *dZ = nullptr, *dR = nullptr, *dV = nullptr, *dmv = nullptr;
+  int rc = decode_hyp(log_hyp, d, 0.0, m);
+  rc |= dev_alloc_t(&dZ, (size_t)M * d);
+  rc |= dev_alloc_t(&dR, szR);
+  rc |= dev_alloc_t(&dV, szR);
+  rc |= dev_alloc_t(&dmv, (size_t)2 * Mpad);
+  std::vector<double> hm(M), hv(M);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (!rc) {
+    do {
+      m->has_y = true;
+      if (hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+      if (hipMemsetAsync(m->dy, 0, (size_t)m->Npad * 8, s) != hipSuccess) { rc = gpk_set_err(-2, "memset failed"); break; }
+      if (hipMemcpyAsync(m->dy, y, (size_t)N * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+      if (hipMemcpyAsync(dZ, Z, (size_t)M * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+      if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "sync failed"); break; }
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      const int saved_timing = G.timing;
+      for (int it = 0; it < warmup + reps && !rc; ++it) {
+        if (it == warmup) {
+          timers_reset();
+          G.timing = saved_timing;
+          (void)hipEventRecord(e0, s);
+        } else if (it < warmup) {
+          G.timing = 0;
+        }
+        rc = fit_device(m);  // includes the 16-byte scalar read-back (the result of compute_likelihood)
+        if (rc) break;
+        rc = predict_device(m, dZ, M, Mpad, dR, dV, dmv, dmv + Mpad);
+        if (rc) break;
+        if (hipMemcpyAsync(hm.data(), dmv, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+        if (hipMemcpyAsync(hv.data(), dmv + Mpad, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "bench: %s", hipGetErrorString(hipGetLastError())); break; }
+      }
+      G.timing = saved_timing;
+      if (rc) break;
+      (void)hipEventRecord(e1, s);
+      (void)hipEventSynchronize(e1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (ms_total_out) *ms_total_out = ms;
+      if (nlml_out) *nlml_out = m->nlml;
+      if (mean_out) std::memcpy(mean_out, hm.data(), (size_t)M * 8);
+      if (var_out) std::memcpy(var_out, hv.data(), (size_t)M * 8);
+    } while (0);
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (dZ) dev_free(dZ, (size_t)M * d * 8);
+  if (dR) dev_free(dR, szR * 8);
+  if (dV) dev_free(dV, szR * 8);
+  if (dmv) dev_free(dmv, (size_t)2 * Mpad * 8);
+  if (rc > 0) gpk_set_err(rc, "kernel matrix is not positive definite (leading minor %d)", rc);
+  model_destroy(m);
+  return rc;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- kernel-level test hooks
+extern "C" {
+
+int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile) {
+  GPK_TRY(rt_require());
+  hipStream_t s = G.s_main;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  GPK_TRY(dev_alloc_t(&dA, (size_t)m * k));
+  GPK_TRY(dev_alloc_t(&dB, (size_t)n * k));
+  GPK_TRY(dev_alloc_t(&dC, (size_t)m * n));
+  int rc = 0;
+  do {
+    if (hipMemcpyAsync(dA, A, (size_t)m * k * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    if (hipMemcpyAsync(dB, B, (size_t)n * k * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    if (hipMemcpyAsync(dC, C, (size_t)m * n * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    GemmNT g{};
+    g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
+    g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
+    rc = launch_gemm_nt(g, tile == 128, s);
+    if (rc) break;
+    if (hipMemcpyAsync(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "test_gemm: %s", hipGetErrorString(hipGetLastError())); break; }
+  } while (0);
+  dev_free(dA, (size_t)m * k * 8);
+  dev_free(dB, (size_t)n * k * 8);
+  dev_free(dC, (size_t)m * n * 8);
+  return rc;
+}
+
+int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out) {
+  GPK_TRY(rt_require());
+  hipStream_t s = G.s_main;
+  double *dA = nullptr, *dL = nullptr, *dD = nullptr;
+  int* dinfo = nullptr;
+  GPK_TRY(dev_alloc_t(&dA, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dL, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dD, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dinfo, 4));
+  int rc = 0, hinfo = 0;
+  do {
+    if (hipMemcpyAsync(dA, A, 128 * 128 * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    if (hipMemsetAsync(dinfo, 0, 16, s) != hipSuccess) { rc = gpk_set_err(-2, "memset failed"); break; }
+    rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, 128, s);
+    if (rc) break;
+    if (hipMemcpyAsync(L_out, dL, 128 * 128 * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    if (hipMemcpyAsync(Dinv_out, dD, 128 * 128 * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    if (hipMemcpyAsync(&hinfo, dinfo, 4, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "test_potf2: %s", hipGetErrorString(hipGetLastError())); break; }
+    rc = hinfo;
+  } while (0);
+  dev_free(dA, 128 * 128 * 8);
+  dev_free(dL, 128 * 128 * 8);
+  dev_free(dD, 128 * 128 * 8);
+  dev_free(dinfo, 16);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// RCCL plumbing: one process per GPU, the communicator lives inside libgpk.so.
+// The host (bench.py / gptest_amd.dist) only ferries the 128-byte unique id.
+// The reference has no distributed code at all; this is the exchange step that
+// BASELINE.json's north_star prescribes (panel broadcast over xGMI).
+#include "../../include/gpk.h"
+#include "gpk_core.h"
+#include <rccl/rccl.h>
+
+#define GPK_NCCL(x)                                                                                          \
+  do {                                                                                                       \
+    ncclResult_t r_ = (x);                                                                                   \
+    if (r_ != ncclSuccess)                                                                                   \
+      return gpk_set_err(-3, "%s failed: %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__);      \
+  } while (0)
+
+static_assert(GPK_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+
+int comm_bcast(double* buf, size_t count, int root, hipStream_t s) {
+  if (G.nranks <= 1) return 0;
+  GPK_NCCL(ncclBroadcast(buf, buf, count, ncclDouble, root, (ncclComm_t)G.nccl, s));
+  return 0;
+}
+
+extern "C" {
+
+int gpk_comm_unique_id(void* out128) {
+  if (!out128) return gpk_set_err(-1, "gpk_comm_unique_id: null pointer");
+  ncclUniqueId id;
+  GPK_NCCL(ncclGetUniqueId(&id));
+  std::memcpy(out128, &id, NCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+int gpk_comm_init(int rank, int nranks, const void* uid128) {
+  GPK_TRY(rt_require());
+  if (G.nccl) return gpk_set_err(-1, "gpk_comm_init: communicator already initialised");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return gpk_set_err(-1, "gpk_comm_init: bad rank %d / %d", rank, nranks);
+  if (nranks == 1) {
+    G.rank = 0;
+    G.nranks = 1;
+    return 0;
+  }
+  if (!uid128) return gpk_set_err(-1, "gpk_comm_init: null unique id");
+  ncclUniqueId id;
+  std::memcpy(&id, uid128, NCCL_UNIQUE_ID_BYTES);
+  ncclComm_t c;
+  GPK_NCCL(ncclCommInitRank(&c, nranks, id, rank));
+  G.nccl = c;
+  G.rank = rank;
+  G.nranks = nranks;
+  return 0;
+}
+
+int gpk_comm_rank(void) { return G.rank; }
+int gpk_comm_size(void) { return G.nranks; }
+
+int gpk_comm_allreduce_max(double* inout, int n) {
+  GPK_TRY(rt_require());
+  if (G.nranks <= 1 || n <= 0) return 0;
+  double* d = nullptr;
+  GPK_TRY(dev_alloc_t(&d, (size_t)n));
+  hipStream_t s = G.s_main;
+  int rc = 0;
+  do {
+    if (hipMemcpyAsync(d, inout, (size_t)n * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    ncclResult_t r = ncclAllReduce(d, d, n, ncclDouble, ncclMax, (ncclComm_t)G.nccl, s);
+    if (r != ncclSuccess) { rc = gpk_set_err(-3, "ncclAllReduce failed: %s", ncclGetErrorString(r)); break; }
+    if (hipMemcpyAsync(inout, d, (size_t)n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "allreduce sync failed"); break; }
+  } while (0);
+  dev_free(d, (size_t)n * 8);
+  return rc;
+}
+
+int gpk_comm_barrier(void) {
+  double x = 0.0;
+  GPK_TRY(gpk_comm_allreduce_max(&x, 1));
+  if (G.inited) GPK_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+int gpk_comm_destroy(void) {
+  if (G.nccl) {
+    (void)hipDeviceSynchronize();
+    ncclCommDestroy((ncclComm_t)G.nccl);
+    G.nccl = nullptr;
+  }
+  G.rank = 0;
+  G.nranks = 1;
+  return 0;
+}
+
+}  // extern "C"

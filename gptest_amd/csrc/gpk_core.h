@@ -1,0 +1,69 @@
+// Host-side runtime of libgpk.so: device binding, streams, a caching device
+// allocator (the optimiser calls gpk_fit hundreds of times: GP_regression_demo.py:44),
+// the model handle and the blocked-Cholesky driver.
+#pragma once
+#include "gpk_internal.h"
+#include <map>
+
+struct StageTimer {
+  struct Rec { hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  double ms = 0.0;
+  double count = 0.0;
+};
+
+struct Runtime {
+  bool inited = false;
+  int device = 0;
+  hipStream_t s_main = nullptr, s_panel = nullptr, s_comm = nullptr;
+  std::map<size_t, std::vector<void*>> pool;
+  size_t pool_bytes = 0;
+  // options
+  int nb = 256;
+  int lookahead = 1;
+  int timing = 0;
+  int small_tile_rows = 4096;  // GEMMs with n == 128 use the 64x64 tile below this many rows... (see potrf)
+  // comm
+  int rank = 0, nranks = 1;
+  void* nccl = nullptr;
+  std::map<std::string, StageTimer> timers;
+  std::vector<hipEvent_t> ev_free;
+};
+extern Runtime G;
+
+int rt_require();
+int dev_alloc(void** p, size_t bytes);
+void dev_free(void* p, size_t bytes);
+template <class T> int dev_alloc_t(T** p, size_t n) { return dev_alloc((void**)p, n * sizeof(T)); }
+
+void timer_begin(const char* stage, hipStream_t s);
+void timer_end(const char* stage, hipStream_t s);
+void timers_reset();
+int timers_resolve();
+
+struct gpk_model {
+  int N = 0, d = 0, Npad = 0, nT = 0, NB = 0, nP = 0;
+  std::vector<int> pc0, pw;
+  std::vector<size_t> poff;
+  size_t L_elems = 0;
+  double *dX = nullptr, *dy = nullptr, *dw = nullptr;
+  double *dK = nullptr, *dKcopy = nullptr, *dL = nullptr, *dDinv = nullptr;
+  double* dscal = nullptr;  // [0] sum log diag L  [1] w.w
+  double* dws = nullptr;    // gemvT workspace 64*NB
+  int* dinfo = nullptr;
+  SEParams se;
+  double sn2 = 0, jitter = 0;
+  double nlml = 0, logdet = 0, quad = 0;
+  int info = 0;
+  bool has_y = false, keep_k = false;
+  double* Lpanel(int p) const { return dL + poff[p]; }
+};
+
+int model_create(gpk_model** out, int N, int d, bool keep_k);
+void model_destroy(gpk_model* m);
+int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m);
+int fit_device(gpk_model* m);                                   // K build + potrf + w + scalars (inputs resident)
+int potrf_device(gpk_model* m);                                 // dK -> dL, dDinv
+int trsv_forward(gpk_model* m, double* v);                      // v <- L^-1 v  (Npad vector)
+int trsv_backward(gpk_model* m, double* v);                     // v <- L^-T v
+int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, double* dV, double* dmean, double* dvar);

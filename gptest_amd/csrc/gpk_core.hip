@@ -1,0 +1,356 @@
+// Runtime + blocked Cholesky driver + fused fit/predict (host side of libgpk.so).
+#include "gpk_core.h"
+#include <cmath>
+
+Runtime G;
+static thread_local std::string g_err = "";
+
+int gpk_set_err(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+const char* gpk_err_cstr() { return g_err.c_str(); }
+
+int rt_require() {
+  if (!G.inited) return gpk_set_err(-1, "gpk_init() has not been called");
+  return 0;
+}
+
+// ------------------------------------------------------------------ allocator
+int dev_alloc(void** p, size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  bytes = (bytes + 255) & ~(size_t)255;
+  auto it = G.pool.find(bytes);
+  if (it != G.pool.end() && !it->second.empty()) {
+    *p = it->second.back();
+    it->second.pop_back();
+    G.pool_bytes -= bytes;
+    return 0;
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    // drop the cache and retry once
+    for (auto& kv : G.pool)
+      for (void* q : kv.second) (void)hipFree(q);
+    G.pool.clear();
+    G.pool_bytes = 0;
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return gpk_set_err(-2, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return 0;
+}
+void dev_free(void* p, size_t bytes) {
+  if (!p) return;
+  if (bytes == 0) bytes = 256;
+  bytes = (bytes + 255) & ~(size_t)255;
+  G.pool[bytes].push_back(p);
+  G.pool_bytes += bytes;
+}
+
+// ------------------------------------------------------------------ timers
+static hipEvent_t ev_get() {
+  if (!G.ev_free.empty()) {
+    hipEvent_t e = G.ev_free.back();
+    G.ev_free.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void timer_begin(const char* stage, hipStream_t s) {
+  if (!G.timing) return;
+  StageTimer& t = G.timers[stage];
+  StageTimer::Rec r;
+  r.a = ev_get();
+  r.b = nullptr;
+  (void)hipEventRecord(r.a, s);
+  t.recs.push_back(r);
+}
+void timer_end(const char* stage, hipStream_t s) {
+  if (!G.timing) return;
+  StageTimer& t = G.timers[stage];
+  if (t.recs.empty()) return;
+  StageTimer::Rec& r = t.recs.back();
+  r.b = ev_get();
+  (void)hipEventRecord(r.b, s);
+}
+void timers_reset() {
+  for (auto& kv : G.timers) {
+    for (auto& r : kv.second.recs) {
+      if (r.a) G.ev_free.push_back(r.a);
+      if (r.b) G.ev_free.push_back(r.b);
+    }
+    kv.second.recs.clear();
+    kv.second.ms = 0;
+    kv.second.count = 0;
+  }
+}
+int timers_resolve() {
+  GPK_HIP(hipDeviceSynchronize());
+  for (auto& kv : G.timers) {
+    StageTimer& t = kv.second;
+    for (auto& r : t.recs) {
+      if (r.a && r.b) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+          t.ms += ms;
+          t.count += 1;
+        }
+      }
+      if (r.a) G.ev_free.push_back(r.a);
+      if (r.b) G.ev_free.push_back(r.b);
+    }
+    t.recs.clear();
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ model
+int model_create(gpk_model** out, int N, int d, bool keep_k) {
+  GPK_TRY(rt_require());
+  if (N < 1) return gpk_set_err(-1, "N=%d must be >= 1", N);
+  if (d < 1 || d > 32) return gpk_set_err(-1, "input dimension d=%d outside 1..32", d);
+  gpk_model* m = new gpk_model();
+  m->N = N;
+  m->d = d;
+  int nb = G.nb;
+  if (nb < 128) nb = 128;
+  nb = nb / 128 * 128;
+  m->NB = nb;
+  m->Npad = (G.nranks > 1) ? round_up(N, nb) : round_up(N, GPK_T);
+  m->nT = m->Npad / GPK_T;
+  size_t off = 0;
+  for (int c0 = 0; c0 < m->Npad; c0 += nb) {
+    int w = std::min(nb, m->Npad - c0);
+    m->pc0.push_back(c0);
+    m->pw.push_back(w);
+    m->poff.push_back(off);
+    off += (size_t)(m->Npad - c0) * w;
+  }
+  m->nP = (int)m->pc0.size();
+  m->L_elems = off;
+  m->keep_k = keep_k;
+  const size_t np = m->Npad;
+  int rc = 0;
+  rc |= dev_alloc_t(&m->dX, (size_t)N * d);
+  rc |= dev_alloc_t(&m->dy, np);
+  rc |= dev_alloc_t(&m->dw, np);
+  rc |= dev_alloc_t(&m->dK, np * np);
+  if (keep_k) rc |= dev_alloc_t(&m->dKcopy, np * np);
+  rc |= dev_alloc_t(&m->dL, m->L_elems);
+  rc |= dev_alloc_t(&m->dDinv, (size_t)m->nT * 128 * 128);
+  rc |= dev_alloc_t(&m->dscal, 8);
+  rc |= dev_alloc_t(&m->dws, (size_t)64 * nb);
+  rc |= dev_alloc_t(&m->dinfo, 4);
+  if (rc) {
+    model_destroy(m);
+    return -2;
+  }
+  *out = m;
+  return 0;
+}
+
+void model_destroy(gpk_model* m) {
+  if (!m) return;
+  const size_t np = m->Npad;
+  dev_free(m->dX, (size_t)m->N * m->d * 8);
+  dev_free(m->dy, np * 8);
+  dev_free(m->dw, np * 8);
+  dev_free(m->dK, np * np * 8);
+  if (m->dKcopy) dev_free(m->dKcopy, np * np * 8);
+  dev_free(m->dL, m->L_elems * 8);
+  dev_free(m->dDinv, (size_t)m->nT * 128 * 128 * 8);
+  dev_free(m->dscal, 64);
+  dev_free(m->dws, (size_t)64 * m->NB * 8);
+  dev_free(m->dinfo, 16);
+  delete m;
+}
+
+// GPr.py:90-97: hyp = exp(logHyp); M = hyp[:n-2]; sf2 = hyp[n-2]^2; sn2 = hyp[n-1]^2
+int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m) {
+  m->se.d = d;
+  for (int k = 0; k < d; ++k) {
+    const double ell = std::exp(log_hyp[k]);
+    if (!(ell > 0.0) || !std::isfinite(ell)) return gpk_set_err(-1, "length scale %d is not positive finite", k);
+    m->se.ell[k] = ell;
+  }
+  const double sf = std::exp(log_hyp[d]), sn = std::exp(log_hyp[d + 1]);
+  m->se.sf2 = sf * sf;
+  m->sn2 = sn * sn;
+  m->jitter = jitter;
+  m->se.diag_add = m->sn2 + jitter;
+  return 0;
+}
+
+// ------------------------------------------------------------------ blocked Cholesky
+// Right-looking over outer panels of width NB (one MFMA SYRK per panel, K = NB keeps the
+// C read-modify-write traffic at 8/NB bytes per flop), left-looking over the 128-wide
+// sub-panels inside a panel.  L goes to its own panel-packed storage (panel p =
+// rows c0.. x w, ld = w): compact operands for every later kernel and no in-place hazard
+// in the panel solve.  Replaces np.linalg.cholesky (GPr.py:62, GPpref.py:128).
+static int factor_panel(gpk_model* m, int p, hipStream_t s) {
+  const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
+  double* Lp = m->Lpanel(p);
+  const int h = np_ - c0;
+  for (int sb = 0; sb < w / 128; ++sb) {
+    const int cs = c0 + sb * 128;   // global column of this sub-panel
+    const int ro = cs - c0;         // row offset inside the panel
+    double* Acol = m->dK + (long)cs * np_ + cs;  // A[cs, cs]
+    if (sb > 0) {
+      // A[cs:, cs:cs+128] -= Lp[ro:, 0:ro] * Lp[ro:ro+128, 0:ro]^T
+      GemmNT g{};
+      g.A = Lp + (long)ro * w; g.lda = w;
+      g.B = Lp + (long)ro * w; g.ldb = w;
+      g.C = Acol; g.ldc = np_;
+      g.m = h - ro; g.n = 128; g.k = ro; g.sub = 1;
+      GPK_TRY(launch_gemm_nt(g, false, s));
+    }
+    double* Dt = m->dDinv + (long)(cs / 128) * 128 * 128;
+    GPK_TRY(launch_potf2_trtri_128(Acol, np_, Lp + (long)ro * w + sb * 128, w, Dt, m->dinfo, cs, 128, s));
+    if (h - ro - 128 > 0) {
+      // L[cs+128:, sub-panel] = A[cs+128:, cs:cs+128] * Dinv^T
+      GemmNT g{};
+      g.A = Acol + (long)128 * np_; g.lda = np_;
+      g.B = Dt; g.ldb = 128;
+      g.C = Lp + (long)(ro + 128) * w + sb * 128; g.ldc = w;
+      g.m = h - ro - 128; g.n = 128; g.k = 128; g.sub = 0;
+      GPK_TRY(launch_gemm_nt(g, false, s));
+    }
+  }
+  return 0;
+}
+
+static int trailing_update(gpk_model* m, int p, int first_tile, int ntiles, hipStream_t s) {
+  // A[c0+w:, c0+w:] (lower tiles) -= Lp[w:, :] * Lp[w:, :]^T, restricted to row/col tiles >= first_tile
+  const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
+  const int h = np_ - c0;
+  const int mm = h - w;
+  if (mm <= 0) return 0;
+  (void)first_tile; (void)ntiles;
+  double* Lp = m->Lpanel(p);
+  GemmNT g{};
+  g.A = Lp + (long)w * w; g.lda = w;
+  g.B = g.A; g.ldb = w;
+  g.C = m->dK + (long)(c0 + w) * np_ + (c0 + w); g.ldc = np_;
+  g.m = mm; g.n = mm; g.k = w; g.sub = 1; g.lower = 1;
+  return launch_gemm_nt(g, true, s);
+}
+
+int potrf_device(gpk_model* m) {
+  hipStream_t s = G.s_main;
+  GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, s));
+  for (int p = 0; p < m->nP; ++p) {
+    timer_begin("panel", s);
+    GPK_TRY(factor_panel(m, p, s));
+    timer_end("panel", s);
+    timer_begin("trailing", s);
+    GPK_TRY(trailing_update(m, p, 0, 0, s));
+    timer_end("trailing", s);
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ triangular solves, single right-hand side
+int trsv_forward(gpk_model* m, double* v) {
+  hipStream_t s = G.s_main;
+  for (int p = 0; p < m->nP; ++p) {
+    const int c0 = m->pc0[p], w = m->pw[p], h = m->Npad - c0;
+    double* Lp = m->Lpanel(p);
+    GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, v + c0, 0, s));
+    GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, v + c0, v + c0 + w, s));
+  }
+  return 0;
+}
+int trsv_backward(gpk_model* m, double* v) {
+  hipStream_t s = G.s_main;
+  for (int p = m->nP - 1; p >= 0; --p) {
+    const int c0 = m->pc0[p], w = m->pw[p], h = m->Npad - c0;
+    double* Lp = m->Lpanel(p);
+    GPK_TRY(launch_gemvT_sub(Lp + (long)w * w, w, h - w, w, v + c0 + w, v + c0, m->dws, s));
+    GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, v + c0, 1, s));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ fused fit (inputs already in HBM)
+int fit_device(gpk_model* m) {
+  hipStream_t s = G.s_main;
+  const int np_ = m->Npad;
+  timer_begin("kbuild", s);
+  GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, np_, m->keep_k ? 0 : 1, s));
+  timer_end("kbuild", s);
+  if (m->keep_k)
+    GPK_HIP(hipMemcpyAsync(m->dKcopy, m->dK, (size_t)np_ * np_ * 8, hipMemcpyDeviceToDevice, s));
+  timer_begin("potrf", s);
+  GPK_TRY(potrf_device(m));
+  timer_end("potrf", s);
+  GPK_TRY(launch_sum_log_diag(m->dDinv, m->N, m->dscal + 0, s));
+  if (m->has_y) {
+    timer_begin("solve_y", s);
+    GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, s));
+    GPK_TRY(trsv_forward(m, m->dw));
+    GPK_TRY(launch_dot(m->dw, m->dw, np_, m->dscal + 1, s));
+    timer_end("solve_y", s);
+  }
+  double hs[2] = {0, 0};
+  int hinfo = 0;
+  GPK_HIP(hipMemcpyAsync(hs, m->dscal, 16, hipMemcpyDeviceToHost, s));
+  GPK_HIP(hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s));
+  GPK_HIP(hipStreamSynchronize(s));
+  m->info = hinfo;
+  if (hinfo > 0) return hinfo > m->N ? m->N : hinfo;
+  m->logdet = hs[0];
+  m->quad = m->has_y ? hs[1] : 0.0;
+  // GPr.py:64-69: err_y + det_Kxx + occams_razor
+  m->nlml = m->has_y ? 0.5 * m->quad + m->logdet + 0.5 * m->N * std::log(2.0 * M_PI) : m->logdet;
+  return 0;
+}
+
+// ------------------------------------------------------------------ prediction (GPr.py:45-54)
+// V = Kzx L^-T by blocked forward substitution on the ROWS of Kzx (the same NT GEMM as the
+// factorisation), then mean_j = V_j . w and var_j = sf2 - |V_j|^2 in one pass.
+int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, double* dV, double* dmean,
+                   double* dvar) {
+  hipStream_t s = G.s_main;
+  const int np_ = m->Npad;
+  timer_begin("predict", s);
+  GPK_TRY(launch_se_build(dZ, M, Mpad, m->dX, m->N, np_, m->se, 0, 0, dR, np_, 0, s));
+  for (int p = 0; p < m->nP; ++p) {
+    const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
+    double* Lp = m->Lpanel(p);
+    for (int sb = 0; sb < w / 128; ++sb) {
+      const int cs = c0 + sb * 128, ro = cs - c0;
+      if (sb > 0) {
+        GemmNT g{};
+        g.A = dV + c0; g.lda = np_;
+        g.B = Lp + (long)ro * w; g.ldb = w;
+        g.C = dR + cs; g.ldc = np_;
+        g.m = Mpad; g.n = 128; g.k = ro; g.sub = 1;
+        GPK_TRY(launch_gemm_nt(g, false, s));
+      }
+      GemmNT g{};
+      g.A = dR + cs; g.lda = np_;
+      g.B = m->dDinv + (long)(cs / 128) * 128 * 128; g.ldb = 128;
+      g.C = dV + cs; g.ldc = np_;
+      g.m = Mpad; g.n = 128; g.k = 128; g.sub = 0;
+      GPK_TRY(launch_gemm_nt(g, false, s));
+    }
+    if (h - w > 0) {
+      GemmNT g{};
+      g.A = dV + c0; g.lda = np_;
+      g.B = Lp + (long)w * w; g.ldb = w;
+      g.C = dR + c0 + w; g.ldc = np_;
+      g.m = Mpad; g.n = h - w; g.k = w; g.sub = 1;
+      GPK_TRY(launch_gemm_nt(g, true, s));
+    }
+  }
+  GPK_TRY(launch_row_stats(dV, np_, M, np_, m->dw, m->se.sf2, dmean, dvar, s));
+  timer_end("predict", s);
+  return 0;
+}

@@ -1,0 +1,83 @@
+// Internal declarations shared by the HIP translation units of libgpk.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define GPK_T 128  // tile edge: every padded dimension is a multiple of this
+
+int gpk_set_err(int code, const char* fmt, ...);
+
+#define GPK_HIP(x)                                                                             \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess)                                                                      \
+      return gpk_set_err(-2, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define GPK_TRY(x)          \
+  do {                      \
+    int r_ = (x);           \
+    if (r_ != 0) return r_; \
+  } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------- GEMM (NT)
+// C[m x n] (op)= A[m x k] * B[n x k]^T, all row-major fp64, MFMA 16x16x4 f64.
+// m, n multiples of the block tile (128 or 64), k multiple of 16.
+struct GemmNT {
+  const double* A; long lda;
+  const double* B; long ldb;
+  double* C; long ldc;
+  int m, n, k;
+  int sub;    // 0: C = A*B^T      1: C = C - A*B^T
+  int lower;  // 1: compute only tiles that touch the lower triangle (global row >= global col)
+  // block-cyclic column map (multi-GPU trailing update). cyc_P == 0 -> identity map.
+  int cyc_P, cyc_r, cyc_NB, cyc_lg0;
+  long row_g0;   // global row index of C row 0
+  long brow_g0;  // global row index of B row 0 (B tile row = gcol(tj) - brow_g0 when cyc_P > 0 or lower)
+};
+// tile128 = true: 128x128 block tile (4x4 MFMA tiles per wave); false: 64x64 (2x2 per wave).
+int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s);
+
+// ---------------------------------------------------------------- leaf factor
+// Factor the 128x128 diagonal tile A (lda) -> L tile (ldl, strict upper zeroed) and
+// Dinv = inv(L) (dense 128x128, ld 128, strict upper zeroed).  *info gets
+// (col0 + j + 1) of the first non-positive pivot (only if it is still 0).
+int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info,
+                           int col0, int n_valid, hipStream_t s);
+
+// ---------------------------------------------------------------- builders
+struct SEParams {
+  int d;
+  double sf2, diag_add;   // diag_add = sn2 + jitter (Kxx only)
+  double ell[32];        // length scales M (GPr.py:95); inputs are divided by them as GPr.py:100 does
+};
+// out[r][c] (ld) for r < nr_pad, c < nc_pad; R (nr x d), Cc (nc x d) device row-major.
+// mode 0: sf2*exp(-0.5*r2) (+diag_add where global r == c if same_set); padded entries: identity if same_set else 0
+// mode 1: plain squared distance r2 (scaled by inv_ell, pass ones for raw)
+int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p,
+                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s);
+
+// ---------------------------------------------------------------- aux kernels
+int launch_sum_log_diag(const double* Dinv, int N, double* out, hipStream_t s);              // -sum log Dinv_ii, i < N
+int launch_dot(const double* a, const double* b, int n, double* out, hipStream_t s);          // deterministic
+int launch_row_stats(const double* X, long ld, int rows, int n, const double* w, double sf2, double* mean,
+                     double* var, hipStream_t s);  // mean_j = X_j . w ; var_j = sf2 - X_j . X_j
+// y = beta*y + alpha*A x  (one wave per row, coalesced);  gemv_sub: y -= A x
+int launch_gemv(const double* A, long lda, int m, int k, const double* x, double* y, double alpha, double beta, hipStream_t s);
+int launch_gemv_sub(const double* A, long lda, int m, int k, const double* x, double* y, hipStream_t s);
+// y[0:k) -= A[m x k]^T x[0:m)  -- column sums, deterministic two-stage (ws >= 64*k doubles)
+int launch_gemvT_sub(const double* A, long lda, int m, int k, const double* x, double* y, double* ws, hipStream_t s);
+// diag-block solves for one panel of width w (multiple of 128) at L (ld w): forward x = Lpp^-1 b ; backward x = Lpp^-T b
+int launch_diag_solve(const double* Lp, int w, const double* Dinv, double* b, int transpose, hipStream_t s);
+int launch_transpose(const double* in, long ldin, int rows, int cols, double* out, long ldout, hipStream_t s);
+int launch_fill(double* p, size_t n, double v, hipStream_t s);
+int launch_unpack_L(const double* Lp, int w, int h, int c0, double* out, long ldout, hipStream_t s);
+int launch_gather2d(const double* K, long ldk, const long long* idx, int nidx, double* out, hipStream_t s);

@@ -1,0 +1,263 @@
+// Memory-bound helpers around the factorisation: reductions, GEMV-shaped
+// substitution steps, transposes, unpacking.  All reductions are deterministic
+// (fixed tree, no float atomics) so repeated runs are bit-identical.
+#include "gpk_internal.h"
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum for <=1024 threads; result valid in thread 0
+__device__ inline double block_sum(double v, double* sm) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = wave_sum(v);
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (w == 0) {
+    r = (lane < (int)(blockDim.x >> 6)) ? sm[lane] : 0.0;
+    r = wave_sum(r);
+  }
+  __syncthreads();
+  return r;
+}
+
+// out = -sum_{i<N} log(Dinv_ii)  == sum log L_ii  (GPr.py:66, GPpref.py:131)
+__global__ void sum_log_diag_kernel(const double* __restrict__ Dinv, int N, double* out) {
+  __shared__ double sm[16];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const int t = i >> 7, r = i & 127;
+    acc -= log(Dinv[(long)t * 128 * 128 + r * 128 + r]);
+  }
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) *out = acc;
+}
+int launch_sum_log_diag(const double* Dinv, int N, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(sum_log_diag_kernel, dim3(1), dim3(1024), 0, s, Dinv, N, out);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void dot_kernel(const double* __restrict__ a, const double* __restrict__ b, int n, double* out) {
+  __shared__ double sm[16];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += a[i] * b[i];
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) *out = acc;
+}
+int launch_dot(const double* a, const double* b, int n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, s, a, b, n, out);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+// one workgroup per row j of X (rows x n, ld): mean_j = X_j . w ; var_j = sf2 - X_j . X_j   (GPr.py:50-53)
+__global__ void row_stats_kernel(const double* __restrict__ X, long ld, int n, const double* __restrict__ w,
+                                 double sf2, double* mean, double* var) {
+  __shared__ double sm[16];
+  const double* x = X + (long)blockIdx.x * ld;
+  double a = 0.0, q = 0.0;
+  for (int i = threadIdx.x * 2; i < n; i += blockDim.x * 2) {
+    const double x0 = x[i], x1 = x[i + 1];
+    a += x0 * w[i] + x1 * w[i + 1];
+    q += x0 * x0 + x1 * x1;
+  }
+  a = block_sum(a, sm);
+  q = block_sum(q, sm);
+  if (threadIdx.x == 0) {
+    mean[blockIdx.x] = a;
+    var[blockIdx.x] = sf2 - q;
+  }
+}
+int launch_row_stats(const double* X, long ld, int rows, int n, const double* w, double sf2, double* mean,
+                     double* var, hipStream_t s) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(row_stats_kernel, dim3(rows), dim3(256), 0, s, X, ld, n, w, sf2, mean, var);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+// y[r] = beta*y[r] + alpha * A[r,:] . x   one wave per row, lanes along k (coalesced)
+__global__ void gemv_kernel(const double* __restrict__ A, long lda, int m, int k, const double* __restrict__ x,
+                            double* __restrict__ y, double alpha, double beta) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const double* a = A + (long)row * lda;
+  double acc = 0.0;
+  for (int i = lane * 2; i < k; i += 128) acc += a[i] * x[i] + a[i + 1] * x[i + 1];
+  acc = wave_sum(acc);
+  if (lane == 0) y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * acc;
+}
+int launch_gemv(const double* A, long lda, int m, int k, const double* x, double* y, double alpha, double beta,
+                hipStream_t s) {
+  if (m <= 0) return 0;
+  if (k & 1) return gpk_set_err(-1, "gemv: k=%d must be even", k);
+  hipLaunchKernelGGL(gemv_kernel, dim3((m + 3) / 4), dim3(256), 0, s, A, lda, m, k, x, y, alpha, beta);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+int launch_gemv_sub(const double* A, long lda, int m, int k, const double* x, double* y, hipStream_t s) {
+  return launch_gemv(A, lda, m, k, x, y, -1.0, 1.0, s);
+}
+
+// column sums: ws[chunk][c] = sum_{r in chunk} A[r][c] * x[r];  then y[c] -= sum_chunk ws[chunk][c]
+#define GT_CHUNKS 64
+__global__ void gemvT_part_kernel(const double* __restrict__ A, long lda, int m, int k, const double* __restrict__ x,
+                                  double* __restrict__ ws) {
+  const int chunk = blockIdx.x;
+  const int rows_per = (m + GT_CHUNKS - 1) / GT_CHUNKS;
+  const int r0 = chunk * rows_per, r1 = min(m, r0 + rows_per);
+  for (int c = threadIdx.x; c < k; c += blockDim.x) {
+    double acc = 0.0;
+    for (int r = r0; r < r1; ++r) acc += A[(long)r * lda + c] * x[r];
+    ws[(long)chunk * k + c] = acc;
+  }
+}
+__global__ void gemvT_fin_kernel(const double* __restrict__ ws, int k, double* __restrict__ y) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  double acc = 0.0;
+  for (int ch = 0; ch < GT_CHUNKS; ++ch) acc += ws[(long)ch * k + c];
+  y[c] -= acc;
+}
+int launch_gemvT_sub(const double* A, long lda, int m, int k, const double* x, double* y, double* ws, hipStream_t s) {
+  if (m <= 0 || k <= 0) return 0;
+  hipLaunchKernelGGL(gemvT_part_kernel, dim3(GT_CHUNKS), dim3(256), 0, s, A, lda, m, k, x, ws);
+  hipLaunchKernelGGL(gemvT_fin_kernel, dim3((k + 255) / 256), dim3(256), 0, s, ws, k, y);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+// In-place solve with the w x w diagonal block of a panel (ld = w), using the inverted 128-tiles.
+//   transpose = 0:  b <- Lpp^-1 b      transpose = 1:  b <- Lpp^-T b
+__global__ __launch_bounds__(256) void diag_solve_kernel(const double* __restrict__ Lp, int w,
+                                                         const double* __restrict__ Dinv, double* __restrict__ b,
+                                                         int transpose) {
+  extern __shared__ double sh[];  // x[w] + t[128]
+  double* x = sh;
+  double* t = sh + w;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ns = w / 128;
+  for (int i = tid; i < w; i += 256) x[i] = b[i];
+  __syncthreads();
+  if (!transpose) {
+    for (int s = 0; s < ns; ++s) {
+      // t = b_s - L[s rows][0 : 128 s] x[0 : 128 s]    (wave per row)
+      for (int r = wv; r < 128; r += 4) {
+        const double* a = Lp + (long)(s * 128 + r) * w;
+        double acc = 0.0;
+        for (int k = lane; k < s * 128; k += 64) acc += a[k] * x[k];
+        acc = wave_sum(acc);
+        if (lane == 0) t[r] = x[s * 128 + r] - acc;
+      }
+      __syncthreads();
+      // x_s = Dinv_s t
+      for (int r = wv; r < 128; r += 4) {
+        const double* a = Dinv + (long)s * 128 * 128 + r * 128;
+        double acc = a[lane] * t[lane] + a[lane + 64] * t[lane + 64];
+        acc = wave_sum(acc);
+        if (lane == 0) x[s * 128 + r] = acc;
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int s = ns - 1; s >= 0; --s) {
+      // t[c] = b_s[c] - sum_{r >= (s+1)*128} L[r][s*128 + c] x[r]     (thread per column, coalesced rows)
+      if (tid < 128) {
+        double acc = 0.0;
+        for (int r = (s + 1) * 128; r < w; ++r) acc += Lp[(long)r * w + s * 128 + tid] * x[r];
+        t[tid] = x[s * 128 + tid] - acc;
+      }
+      __syncthreads();
+      // x_s[c] = sum_r Dinv_s[r][c] t[r]
+      if (tid < 128) {
+        const double* a = Dinv + (long)s * 128 * 128;
+        double acc = 0.0;
+        for (int r = tid; r < 128; ++r) acc += a[r * 128 + tid] * t[r];
+        x[s * 128 + tid] = acc;
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < w; i += 256) b[i] = x[i];
+}
+int launch_diag_solve(const double* Lp, int w, const double* Dinv, double* b, int transpose, hipStream_t s) {
+  hipLaunchKernelGGL(diag_solve_kernel, dim3(1), dim3(256), (w + 128) * sizeof(double), s, Lp, w, Dinv, b, transpose);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+// out[c][r] = in[r][c] through a 32x33 LDS tile
+__global__ void transpose_kernel(const double* __restrict__ in, long ldin, int rows, int cols, double* __restrict__ out,
+                                 long ldout) {
+  __shared__ double tl[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tl[j][tx] = (r < rows && c < cols) ? in[(long)r * ldin + c] : 0.0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
+    if (c < cols && r < rows) out[(long)c * ldout + r] = tl[tx][j];
+  }
+}
+int launch_transpose(const double* in, long ldin, int rows, int cols, double* out, long ldout, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 0;
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, in, ldin, rows, cols,
+                     out, ldout);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void fill_kernel(double* p, size_t n, double v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+int launch_fill(double* p, size_t n, double v, hipStream_t s) {
+  if (n == 0) return 0;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+// panel (h x w, ld w, first global row/col = c0) -> dense lower-triangular out (ld ldout)
+__global__ void unpack_L_kernel(const double* __restrict__ Lp, int w, int h, int c0, double* __restrict__ out, long ldout,
+                                int nmax) {
+  const int r = blockIdx.x;  // row inside the panel
+  const int gr = c0 + r;
+  if (gr >= nmax) return;
+  for (int c = threadIdx.x; c < w; c += blockDim.x) {
+    const int gc = c0 + c;
+    if (gc >= nmax) continue;
+    out[(long)gr * ldout + gc] = (gc <= gr) ? Lp[(long)r * w + c] : 0.0;
+  }
+}
+int launch_unpack_L(const double* Lp, int w, int h, int c0, double* out, long ldout, hipStream_t s) {
+  // rows beyond ldout (= N) are padding and are skipped inside the kernel via nmax = ldout
+  hipLaunchKernelGGL(unpack_L_kernel, dim3(h), dim3(256), 0, s, Lp, w, h, c0, out, ldout, (int)ldout);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+// out[p*n + q] = K[idx[p]][idx[q]]
+__global__ void gather2d_kernel(const double* __restrict__ K, long ldk, const long long* __restrict__ idx, int n,
+                                double* __restrict__ out) {
+  const int p = blockIdx.x;
+  const long long rp = idx[p];
+  for (int q = threadIdx.x; q < n; q += blockDim.x) out[(long)p * n + q] = K[rp * ldk + idx[q]];
+}
+int launch_gather2d(const double* K, long ldk, const long long* idx, int nidx, double* out, hipStream_t s) {
+  if (nidx <= 0) return 0;
+  hipLaunchKernelGGL(gather2d_kernel, dim3(nidx), dim3(256), 0, s, K, ldk, idx, nidx, out);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}

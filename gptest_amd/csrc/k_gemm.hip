@@ -1,0 +1,158 @@
+// fp64 MFMA GEMM, "NT" form:  C[m x n] (op)= A[m x k] * B[n x k]^T   (all row-major).
+//
+// This one kernel is the Cholesky trailing update (A = B = factored panel, lower
+// tiles only: SYRK), the panel solve (B = inverse of the diagonal tile) and the
+// forward-substitution update of the prediction solve.  It replaces the LAPACK
+// potrf/getrf interior of np.linalg.cholesky / inv / solve at GPr.py:48,62-63.
+//
+// CDNA4 mapping
+//   * v_mfma_f64_16x16x4_f64: 2048 flop / 64 cycles / SIMD = the fp64 peak
+//     (78.6 TFLOP/s chip-wide).  One MFMA consumes ONE f64 of A and ONE of B per
+//     lane, so a wave that register-blocks 4x4 MFMA tiles (64x64 outputs) needs
+//     8 ds_read_b64 per 16 MFMAs (1024 cycles): LDS and L2 are nowhere near a
+//     bound, the matrix pipe is.  4 waves (2x2) -> 128x128 block tile.
+//   * A/B fragment: lane l holds M[r0 + (l&15)][k0 + (l>>4)]  (both operands are
+//     k-contiguous, so A and B use the same LDS image and the same read).
+//   * C/D fragment (f64 only!): col = lane&15, row = (lane>>4) + 4*reg.
+//   * LDS row stride BK+2 doubles: the 32 lanes of a ds_read_b64 group touch
+//     dword banks 36*r + 2*g (+0,1) mod 64 -> all 64 banks once: conflict-free.
+//   * 2 workgroups per CU (<=256 VGPR, 72 KiB LDS each) so one workgroup's C
+//     read-modify-write epilogue overlaps the other's MFMA main loop.
+#include "gpk_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define BK 16
+#define LDS_LD (BK + 2)
+
+template <int WT>  // MFMA tiles per wave per dimension: 4 -> 128x128 block, 2 -> 64x64 block
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
+  constexpr int BT = 2 * WT * 16;       // block tile edge
+  constexpr int PASSES = BT / 32;       // 32 rows of 16 doubles per pass with 256 threads
+  __shared__ double lds[2 * 2 * BT * LDS_LD];
+  double* As = lds;                     // [2][BT][LDS_LD]
+  double* Bs = lds + 2 * BT * LDS_LD;   // [2][BT][LDS_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  // ---- tile decode
+  int ti, tj;
+  const int ntn = g.n / BT;
+  if (g.lower && g.cyc_P == 0) {
+    int id = blockIdx.x;
+    int t = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+    while (t * (t + 1) / 2 > id) --t;
+    while ((t + 1) * (t + 2) / 2 <= id) ++t;
+    ti = t;
+    tj = id - t * (t + 1) / 2;
+  } else {
+    ti = blockIdx.x / ntn;
+    tj = blockIdx.x % ntn;
+  }
+  long brow0;  // first row of the B tile
+  if (g.cyc_P > 0) {
+    const int tpb = g.cyc_NB / BT;
+    long gcol = ((long)(tj / tpb + g.cyc_lg0) * g.cyc_P + g.cyc_r) * g.cyc_NB + (long)(tj % tpb) * BT;
+    if (g.lower && gcol > g.row_g0 + (long)ti * BT) return;  // tile entirely above the diagonal
+    brow0 = gcol - g.brow_g0;
+  } else {
+    brow0 = (long)tj * BT;
+  }
+  const double* Ag = g.A + (long)ti * BT * g.lda;
+  const double* Bg = g.B + brow0 * g.ldb;
+
+  // ---- global -> register staging: 16-byte chunks, 8 chunks per 128-byte row segment
+  const int lrow = tid >> 3;        // 0..31
+  const int lchk = (tid & 7) * 2;   // double offset inside the BK row
+  d2 ra[PASSES], rb[PASSES];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      ra[p] = *reinterpret_cast<const d2*>(Ag + (long)(p * 32 + lrow) * g.lda + kt * BK + lchk);
+      rb[p] = *reinterpret_cast<const d2*>(Bg + (long)(p * 32 + lrow) * g.ldb + kt * BK + lchk);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      *reinterpret_cast<d2*>(As + (buf * BT + p * 32 + lrow) * LDS_LD + lchk) = ra[p];
+      *reinterpret_cast<d2*>(Bs + (buf * BT + p * 32 + lrow) * LDS_LD + lchk) = rb[p];
+    }
+  };
+
+  d4 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int nk = g.k / BK;
+  const int fr = lane & 15, fg = lane >> 4;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const double* Ab = As + (buf * BT + wm * WT * 16 + fr) * LDS_LD + fg;
+    const double* Bb = Bs + (buf * BT + wn * WT * 16 + fr) * LDS_LD + fg;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double a[WT], b[WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) a[i] = Ab[i * 16 * LDS_LD + kk];
+#pragma unroll
+      for (int j = 0; j < WT; ++j) b[j] = Bb[j * 16 * LDS_LD + kk];
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&15, row = (lane>>4) + 4*reg
+  double* Cg = g.C + ((long)ti * BT + wm * WT * 16) * g.ldc + (long)tj * BT + wn * WT * 16;
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* p = Cg + (long)(i * 16 + fg + 4 * r) * g.ldc + j * 16 + fr;
+        if (g.sub)
+          *p = *p - acc[i][j][r];
+        else
+          *p = acc[i][j][r];
+      }
+    }
+  }
+}
+
+int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
+  const int BT = tile128 ? 128 : 64;
+  if (g.m <= 0 || g.n <= 0) return 0;
+  if (g.m % BT || g.n % BT || g.k % BK || g.k <= 0)
+    return gpk_set_err(-1, "gemm_nt: bad shape m=%d n=%d k=%d (tile %d)", g.m, g.n, g.k, BT);
+  if ((g.lda & 1) || (g.ldb & 1) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15))
+    return gpk_set_err(-1, "gemm_nt: operands must be 16-byte aligned with even leading dimensions");
+  const int ntm = g.m / BT, ntn = g.n / BT;
+  long nblk;
+  if (g.lower && g.cyc_P == 0) {
+    if (g.m != g.n) return gpk_set_err(-1, "gemm_nt: lower needs a square C (m=%d n=%d)", g.m, g.n);
+    nblk = (long)ntm * (ntm + 1) / 2;
+  } else {
+    nblk = (long)ntm * ntn;
+  }
+  if (tile128)
+    hipLaunchKernelGGL(gemm_nt_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, g);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,112 @@
+/*
+ * gpk.h -- C ABI of the MI355X-native GP posterior core (libgpk.so).
+ *
+ * The reference (osurdml/GPtest) has no FFI: its boundary is the Python module
+ * surface of GPr.py / GPpref.py.  This header is the boundary a replacement
+ * shared library must export; gptest_amd/GPr.py and gptest_amd/GPpref.py bind
+ * it with ctypes.  Every entry point cites the reference
+ * interface it replaces.
+ *
+ * Conventions
+ *   - all pointers are caller-owned HOST memory, C-contiguous (row-major) fp64
+ *     unless noted; inputs are never modified unless documented;
+ *   - return 0 = ok; < 0 = API / HIP / RCCL error (text via gpk_last_error());
+ *     > 0 = LAPACK-style "leading minor of order k is not positive definite"
+ *     (the Python side raises numpy.linalg.LinAlgError, which is the only
+ *     error the reference handles: GPpref.py:126-135);
+ *   - blocking, one HIP device per process, handles are not thread-safe
+ *     (the reference is single-threaded);
+ *   - log_hyp layout = log([l_1..l_d, sigma_f, sigma_n])  (GPr.py:90-97).
+ *     A log sigma_n of -inf gives sn2 = 0 (GPpref's noise-free K, GPpref.py:122).
+ */
+#ifndef GPK_H
+#define GPK_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPK_ABI_VERSION 1
+#define GPK_UNIQUE_ID_BYTES 128
+
+/* ---- runtime ------------------------------------------------------------ */
+int         gpk_abi_version(void);
+int         gpk_device_count(void);          /* no HIP context is created   */
+int         gpk_init(int device);            /* bind this process to a GPU  */
+void        gpk_shutdown(void);
+const char* gpk_last_error(void);
+int         gpk_sync(void);                  /* hipDeviceSynchronize        */
+int         gpk_set_option(const char* key, double value); /* "nb","lookahead",... */
+double      gpk_get_option(const char* key);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */
+/* rank 0 calls gpk_comm_unique_id, the host broadcasts the 128 bytes by any
+ * means (bench.py: torch.distributed/gloo), every rank calls gpk_comm_init.  */
+int gpk_comm_unique_id(void* out128);
+int gpk_comm_init(int rank, int nranks, const void* uid128);
+int gpk_comm_rank(void);
+int gpk_comm_size(void);
+int gpk_comm_barrier(void);
+int gpk_comm_allreduce_max(double* inout, int n);   /* host doubles, via device */
+int gpk_comm_destroy(void);
+
+/* ---- element-wise builders ------------------------------------------------ */
+/* squared_distance(A,B): GPr.py:4-13 (dup GPpref.py:13-22), extended to (n,d). */
+int gpk_sqdist(const double* A, int n, const double* B, int m, int d, double* out /* n*m */);
+/* SquaredExponential.compute_Kxx_matrix: GPr.py:99-103.  K = (sn2+jitter) I + sf2 exp(-D/2). */
+int gpk_se_kxx(const double* X, int N, int d, const double* log_hyp, double jitter, double* K_out /* N*N */);
+/* SquaredExponential.compute_Kxz_matrix: GPr.py:105-110. */
+int gpk_se_kxz(const double* X, int N, const double* Z, int M, int d, const double* log_hyp, double* Kxz_out /* N*M */);
+
+/* ---- factorisation -------------------------------------------------------- */
+/* np.linalg.cholesky(A): GPr.py:62, GPpref.py:128.  In: symmetric (lower read);
+ * out: lower-triangular L, strict upper zeroed.                               */
+int gpk_potrf(double* A, int N);
+
+/* ---- fused model entry points --------------------------------------------- */
+typedef struct gpk_model gpk_model;
+
+/* GaussianProcess.compute_likelihood: GPr.py:57-69.  Builds K on the device,
+ * factors it, w = L^-1 y, nlml = w.w/2 + sum log L_ii + N log(2 pi)/2.  K and L
+ * stay in HBM behind the handle.  y may be NULL (factor only; nlml_out gets
+ * sum log L_ii, the reference's "logdetK" of GPpref.py:131).
+ * flags: bit0 = keep an unfactored copy of K in HBM (needed by gpk_kmatvec / gpk_kgather). */
+int gpk_fit(const double* X, const double* y, int N, int d, const double* log_hyp,
+            double jitter, int flags, gpk_model** handle_out, double* nlml_out);
+/* GaussianProcess.compute_prediction: GPr.py:45-54.  mean = Kzx K^-1 y,
+ * var = sf2 - diag(Kzx K^-1 Kxz)  (latent variance, no +sn2: GPr.py:51).      */
+int gpk_predict(gpk_model* h, const double* Z, int M, double* mean_out, double* var_out);
+/* K^-1 B for B (N, nrhs) row-major: replaces the explicit iK of GPr.py:63 / GPpref.py:129. */
+int gpk_solve(gpk_model* h, const double* B, int nrhs, double* X_out);
+/* L^-1 B (forward substitution only), B (N, nrhs) row-major. */
+int gpk_solve_lower(gpk_model* h, const double* B, int nrhs, double* X_out);
+/* K B with the kept copy of K (jittered/noisy diagonal included), B (N, nrhs). */
+int gpk_kmatvec(gpk_model* h, const double* B, int nrhs, double* out);
+/* out[p*nidx+q] = K[idx[p], idx[q]] from the kept copy (GPpref Newton step, GPpref.py:142-143). */
+int gpk_kgather(gpk_model* h, const long long* idx, int nidx, double* out);
+/* scalars of the last fit: which = 0 nlml, 1 sum log L_ii, 2 y^T K^-1 y, 3 sf2, 4 sn2. */
+int gpk_model_scalar(gpk_model* h, int which, double* out);
+/* copy L out as dense lower-triangular (N,N) row-major. */
+int gpk_model_get_L(gpk_model* h, double* L_out);
+int gpk_free(gpk_model* h);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------- */
+/* HIP-event timings (ms) of the stages of the last gpk_fit / gpk_predict on this
+ * process; names: "kbuild","potrf","trailing","panel","solve_y","predict".      */
+int gpk_last_timing(const char* stage, double* ms_out, double* count_out);
+/* Stage inputs once (X,y,Z resident in HBM) and run fit+predict `reps` times
+ * without any host<->device traffic inside the timed region; returns total ms.  */
+int gpk_bench_posterior(const double* X, const double* y, int N, int d, const double* log_hyp,
+                        const double* Z, int M, int warmup, int reps, double* ms_total_out,
+                        double* nlml_out, double* mean_out, double* var_out);
+
+/* ---- kernel-level test hooks (tests/ only; host buffers, row-major) --------- */
+/* C (m x n) = [C -] A (m x k) * B (n x k)^T through the MFMA kernel; tile = 128 or 64. */
+int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile);
+/* factor one 128x128 SPD tile: L_out (128x128 lower) and Dinv_out = inv(L). Returns info. */
+int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPK_H */
