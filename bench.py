@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GP posterior solves / second at N=16384, d=8 (BASELINE.json).
+
+One "step" = one GP posterior = compute_likelihood (GPr.py:57-69) + compute_prediction for
+M=1024 test points (GPr.py:45-54) sharing one K build and one Cholesky, on the SURVEY 8(d)
+synthetic inputs, with X, y, Z already resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: the SAME N=16384 posterior is sharded (block-cyclic panels, RCCL panel broadcast over xGMI):
+total work fixed -> "scaling": "strong".  torch.distributed (gloo) is used only to ferry the
+ncclUniqueId and for the final max-over-ranks; all compute is in libgpk.so.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6  # vendor dense fp64 matrix peak, MI355X (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_problem(N, d, M, seed=1234):
+    """SURVEY.md 8(d) inputs (same generator as oracle.gpr_oracle.synthetic_problem)."""
+    rng = np.random.RandomState(seed)
+    X = rng.random_sample((N, d))
+    w = rng.randn(d)
+    y = np.sin(X @ w) + 0.1 * rng.randn(N)
+    Z = rng.random_sample((M, d))
+    log_hyp = np.log([0.7] * d + [1.0, 0.1])
+    return X, y, Z, log_hyp
+
+
+def cpu_baseline(N, d, M, budget_n=4096):
+    """The oracle (verbatim-cost restatement of GPr.py) timed on the host cores, on a bounded
+    sample: one posterior at N_s = budget_n, scaled by (N/N_s)^3 (all dominant terms are n^3)."""
+    from oracle import gpr_oracle as orc
+
+    X, y, Z, lh = orc.synthetic_problem(budget_n, d, M)
+    t0 = time.perf_counter()
+    orc.posterior_verbatim(lh, X, y, Z)
+    t = time.perf_counter() - t0
+    scale = (N / float(budget_n)) ** 3
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {
+        "value": 1.0 / (t * scale),
+        "unit": "posteriors/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "one verbatim-cost posterior (inv + cholesky + 2 LU solves, GPr.py:45-69) at N=%d d=%d M=%d "
+                  "took %.2f s; n^3-scaled x%.0f to N=%d" % (budget_n, d, M, t, scale, N),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--m", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from gptest_amd import _lib, dist
+
+    rank, local, world = dist.env_rank()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    pg = None
+    if world > 1:
+        import torch.distributed as tdist
+
+        tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        pg = tdist
+    dist.init_comm(rank, world, device=local)
+    l = _lib.lib()
+    N, d, M = args.n, args.d, args.m
+    X, y, Z, lh = synthetic_problem(N, d, M)
+    P = _lib.c_double_p
+    ms = ctypes.c_double()
+    nlml = ctypes.c_double()
+    mean = np.zeros(M)
+    var = np.zeros(M)
+    _lib.check(l.gpk_set_option(b"timing", 1.0), "timing")
+
+    # barrier + device sync on both sides of the timed region (gpk_bench_posterior stages the inputs,
+    # runs `warmup` untimed steps, then times exactly `steps` steps with HIP events on its stream).
+    if pg:
+        pg.barrier()
+    _lib.check(l.gpk_sync(), "sync")
+    t0 = time.perf_counter()
+    rc = l.gpk_bench_posterior(X.ctypes.data_as(P), y.ctypes.data_as(P), N, d, lh.ctypes.data_as(P),
+                               Z.ctypes.data_as(P), M, args.warmup, args.steps, ctypes.byref(ms),
+                               ctypes.byref(nlml), mean.ctypes.data_as(P), var.ctypes.data_as(P))
+    _lib.check(rc, "gpk_bench_posterior")
+    _lib.check(l.gpk_sync(), "sync")
+    wall = time.perf_counter() - t0
+    t_ms = ms.value
+    if pg:
+        import torch
+
+        tt = torch.tensor([t_ms], dtype=torch.float64)
+        pg.all_reduce(tt, op=pg.ReduceOp.MAX)
+        t_ms = float(tt[0])
+        pg.barrier()
+
+    def stage(name):
+        a, c = ctypes.c_double(), ctypes.c_double()
+        l.gpk_last_timing(name.encode(), ctypes.byref(a), ctypes.byref(c))
+        return a.value, c.value
+
+    if rank == 0:
+        nb = int(l.gpk_get_option(b"nb"))
+        tr_ms, tr_n = stage("trailing")
+        kb_ms, kb_n = stage("kbuild")
+        npad = (N + nb - 1) // nb * nb if world > 1 else (N + 127) // 128 * 128
+        # algorithmic flops of the trailing (SYRK) updates of ONE factorisation: sum_p m_p^2 * w_p
+        flops = 0.0
+        c0 = 0
+        while c0 < npad:
+            w = min(nb, npad - c0)
+            m_p = npad - c0 - w
+            flops += float(m_p) * m_p * w
+            c0 += w
+        flops_total = flops * args.steps / world  # per rank: every rank updates 1/world of the tiles
+        ach = flops_total / (tr_ms * 1e-3) / 1e12 if tr_ms > 0 else 0.0
+        out = {
+            "metric": "GP posterior solves/sec (N=16384, d=8, M=1024; fit + predict sharing one Cholesky)",
+            "value": args.steps / (t_ms * 1e-3),
+            "unit": "posteriors/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": t_ms / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "GPr regression N=%d d=%d RBF fp64, M=%d test points (BASELINE configs[2])" % (N, d, M),
+                       "panel_width": nb, "parallelism": "1 GPU" if world == 1 else "block-cyclic panels x%d, RCCL broadcast" % world},
+            "roofline": {"kernel": "gemm_nt_kernel (Cholesky trailing update, fp64 MFMA 16x16x4)", "bound": "mfma",
+                         "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "launches": tr_n, "avg_launch_ms": tr_ms / tr_n if tr_n else None,
+                         "alg_flops_per_factorisation": flops},
+            "kbuild": {"bound": "hbm", "ms": kb_ms / kb_n if kb_n else None, "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                       "achieved": (4.0 * npad * npad + 8.0 * N * d) / (kb_ms / kb_n * 1e-3) / 1e9 if kb_n else None,
+                       "note": "lower-triangle tiles only are written: 4*N^2 bytes"},
+            "nlml": nlml.value,
+            "wall_s_incl_staging": wall,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, d, M)
+        print(json.dumps(out))
+    if pg:
+        pg.barrier()
+        pg.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

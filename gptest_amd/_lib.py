@@ -58,6 +58,8 @@ def _bind(l):
         "gpk_bench_posterior": (i, [dp, dp, i, i, dp, dp, i, i, i, dp, dp, dp, dp]),
         "gpk_test_gemm_nt": (i, [dp, dp, dp, i, i, i, i, i, i]),
         "gpk_test_potf2_128": (i, [dp, dp, dp]),
+        "gpk_bench_gemm_nt": (i, [i, i, i, i, i, i, dp]),
+        "gpk_bench_mfma_peak": (i, [i, dp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(l, name)  # AttributeError here = header/library mismatch

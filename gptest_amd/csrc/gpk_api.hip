@@ -491,3 +491,84 @@ int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- micro-benchmarks
+typedef double d4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters, double seed) {
+  d4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (d4_t){0, 0, 0, 0};
+  double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" {
+
+int gpk_bench_mfma_peak(int iters, double* tflops_out) {
+  GPK_TRY(rt_require());
+  hipStream_t s = G.s_main;
+  const int blocks = 256 * 2;  // 2 workgroups of 4 waves per CU
+  double* d = nullptr;
+  GPK_TRY(dev_alloc_t(&d, (size_t)blocks * 256));
+  hipEvent_t e0, e1;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, d, iters / 10 + 1, 0.5);
+  GPK_HIP(hipEventRecord(e0, s));
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, d, iters, 0.5);
+  GPK_HIP(hipEventRecord(e1, s));
+  GPK_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * 4 /*waves*/ * (double)iters * 8 * 2048.0;
+  if (tflops_out) *tflops_out = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dev_free(d, (size_t)blocks * 256 * 8);
+  return 0;
+}
+
+int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out) {
+  GPK_TRY(rt_require());
+  hipStream_t s = G.s_main;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  GPK_TRY(dev_alloc_t(&dA, (size_t)m * k));
+  GPK_TRY(dev_alloc_t(&dC, (size_t)m * n));
+  if (!lower) GPK_TRY(dev_alloc_t(&dB, (size_t)n * k));
+  // random-ish operands (DVFS: zero operands read high, guide rule 25)
+  std::vector<double> h((size_t)std::max(m, n) * k);
+  unsigned long long st = 88172645463325252ull;
+  for (auto& v : h) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = ((double)(st >> 11) / 9007199254740992.0 - 0.5) * 1e-3; }
+  GPK_HIP(hipMemcpyAsync(dA, h.data(), (size_t)m * k * 8, hipMemcpyHostToDevice, s));
+  if (!lower) GPK_HIP(hipMemcpyAsync(dB, h.data(), (size_t)n * k * 8, hipMemcpyHostToDevice, s));
+  GPK_TRY(launch_fill(dC, (size_t)m * n, 1.0, s));
+  GemmNT g{};
+  g.A = dA; g.lda = k; g.B = lower ? dA : dB; g.ldb = k; g.C = dC; g.ldc = n;
+  g.m = m; g.n = n; g.k = k; g.sub = 1; g.lower = lower;
+  int rc = launch_gemm_nt(g, tile == 128, s);
+  hipEvent_t e0, e1;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  GPK_HIP(hipEventRecord(e0, s));
+  for (int r = 0; r < reps && !rc; ++r) rc = launch_gemm_nt(g, tile == 128, s);
+  GPK_HIP(hipEventRecord(e1, s));
+  GPK_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (ms_out) *ms_out = ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dev_free(dA, (size_t)m * k * 8);
+  dev_free(dC, (size_t)m * n * 8);
+  if (dB) dev_free(dB, (size_t)n * k * 8);
+  return rc;
+}
+
+}  // extern "C"

@@ -70,6 +70,7 @@ class PrefProbit(object):
         W = np.zeros((nx, nx), dtype="float")
         for uvik, ddpy_df in zip(uvi, inner):
             xi, yi = uvik
+            ddpy_df = ddpy_df.item() if hasattr(ddpy_df, 'item') else ddpy_df
             W[xi, xi] -= ddpy_df
             W[yi, yi] -= ddpy_df
             W[xi, yi] -= -ddpy_df

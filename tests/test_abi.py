@@ -1,0 +1,72 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/gpk.h declares
+(no compute calls: there is no GPU here), and the product path fails loudly without one."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "gpk.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpk_[A-Za-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gptest_amd import _lib
+
+    l = _lib.lib()
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(l, n), "libgpk.so does not export %s" % n
+    # and the Python binding table covers the header (no silently unbound entry points)
+    assert set(names) == set(_lib.EXPORTS.keys())
+    assert l.gpk_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    from gptest_amd import _lib, GPr
+
+    if _lib.lib().gpk_device_count() > 0:
+        pytest.skip("a GPU is visible; the no-device failure mode cannot be exercised")
+    gp = GPr.GaussianProcess(np.log([1, 1, 0.1]), 0, 0, "SE", "zero", "zero", np.linspace(0, 1, 5), np.zeros(5))
+    with pytest.raises(_lib.GpkError):
+        gp.compute_likelihood(np.log([1, 1, 0.1]))
+    with pytest.raises(_lib.GpkError):
+        GPr.squared_distance(np.zeros(3), np.zeros(3))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under gptest_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gptest_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in src.replace("oracle is", ""), "%s mentions the oracle" % f
+                assert "/root/reference" not in src
+
+
+def test_gpr_surface_matches_reference_names():
+    """Constructor attributes and class names of GPr.py:16-42,72-97 (no GPU needed)."""
+    from gptest_amd import GPr
+
+    lh = np.log([0.5, 2.0, 0.1])
+    x = np.linspace(0, 1, 7)
+    y = np.sin(x)
+    gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", x, y)
+    for a in ("log_hyp", "mean_hyp", "like_hyp", "covFunName", "meanFunName", "likeFunName", "trainInput",
+              "trainTarget", "covFun", "meanFun", "likeFun"):
+        assert hasattr(gp, a)
+    cf = gp.covFun
+    assert isinstance(cf, GPr.SquaredExponential) and isinstance(cf, GPr.CovarianceFunction)
+    np.testing.assert_allclose(cf.M, [0.5])
+    assert cf.sf2 == pytest.approx(4.0) and cf.sn2 == pytest.approx(0.01)
+    assert cf.x is x and cf.logHyp is lh
+    assert gp.meanFun.y == 0 and gp.likeFun.y == 1.0
+    # unknown names silently give [] exactly like GPr.py:31-42
+    gp2 = GPr.GaussianProcess(lh, 0, 0, "XX", "YY", "ZZ", x, y)
+    assert gp2.covFun == [] and gp2.meanFun == [] and gp2.likeFun == []

@@ -1,0 +1,272 @@
+"""GPU parity tests (the real gate): the HIP path, called through the C-ABI / the GPr drop-in,
+against (1) golden vectors produced by the real reference, (2) the pinned oracle on seeded inputs
+at sizes it finishes in seconds, (3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances: BASELINE.json north_star = 1e-6 relative fp64.  Variances are compared relative to sf2
+(cancellation near training points); everything measured sits near 1e-12.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+def _ptr(a):
+    from gptest_amd import _lib
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+# ----------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("m,n,k,tile,sub,lower", [
+    (128, 128, 16, 128, 0, 0), (256, 384, 48, 128, 1, 0), (64, 192, 16, 64, 0, 0),
+    (256, 128, 128, 64, 1, 0), (512, 512, 256, 128, 1, 1), (256, 256, 32, 64, 1, 1),
+])
+def test_mfma_gemm_nt(gpk, m, n, k, tile, sub, lower):
+    """A = I check with ASYMMETRIC B is covered by random operands vs NumPy (fp64, exact to rounding)."""
+    rng = np.random.RandomState(m + n + k)
+    A = rng.randn(m, k)
+    B = A.copy() if lower else rng.randn(n, k)
+    C0 = rng.randn(m, n)
+    C = C0.copy()
+    rc = gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, tile)
+    assert rc == 0, gpk.last_error()
+    ref = C0 - A @ B.T if sub else A @ B.T
+    if lower:
+        mask = np.zeros((m, n), bool)
+        for ti in range(m // tile):
+            mask[ti * tile:(ti + 1) * tile, :(ti + 1) * tile] = True
+        np.testing.assert_allclose(C[mask], ref[mask], rtol=1e-12, atol=1e-12)
+        np.testing.assert_array_equal(C[~mask], C0[~mask])  # tiles above the diagonal untouched
+    else:
+        np.testing.assert_allclose(C, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_mfma_fragment_layout_identity(gpk):
+    """The f64 MFMA C/D map differs from every other dtype (guide section 3): A = I, asymmetric B."""
+    A = np.zeros((128, 16))
+    A[:16, :16] = np.eye(16)
+    B = np.arange(128 * 16, dtype=float).reshape(128, 16) + 0.25
+    C = np.zeros((128, 128))
+    assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 128, 128, 16, 0, 0, 128) == 0
+    np.testing.assert_array_equal(C, A @ B.T)
+
+
+def test_leaf_factor_and_inverse(gpk):
+    rng = np.random.RandomState(3)
+    Q = rng.randn(128, 128)
+    A = Q @ Q.T + 128 * np.eye(128)
+    L = np.zeros((128, 128))
+    D = np.zeros((128, 128))
+    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D)) == 0
+    Lr = np.linalg.cholesky(A)
+    np.testing.assert_allclose(L, Lr, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(D @ Lr, np.eye(128), atol=1e-12)
+    assert np.all(np.triu(L, 1) == 0) and np.all(np.triu(D, 1) == 0)
+    # first non-positive pivot is reported LAPACK-style (1-based)
+    A[7, 7] = -3.0
+    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D)) == 8
+    A[:] = np.nan
+    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D)) == 1
+
+
+@pytest.mark.parametrize("N", [1, 2, 5, 127, 128, 129, 300, 640, 1111, 2048])
+def test_potrf_matches_numpy(gpk, N):
+    rng = np.random.RandomState(N)
+    Q = rng.randn(N, N)
+    A = Q @ Q.T + N * np.eye(N)
+    Ain = A.copy()
+    rc = gpk.lib().gpk_potrf(_ptr(Ain), N)
+    assert rc == 0, gpk.last_error()
+    Lr = np.linalg.cholesky(A)
+    np.testing.assert_allclose(Ain, Lr, rtol=1e-11, atol=1e-11 * np.abs(Lr).max())
+    assert np.all(np.triu(Ain, 1) == 0)
+
+
+@pytest.mark.parametrize("N,bad", [(5, 3), (300, 131), (520, 519)])
+def test_potrf_not_positive_definite(gpk, N, bad):
+    """LAPACK-style info > 0 -> the binding raises numpy.linalg.LinAlgError (what GPpref.py:133 catches)."""
+    A = np.eye(N) * 2.0
+    A[bad, bad] = -1.0
+    rc = gpk.lib().gpk_potrf(_ptr(A), N)
+    assert rc == bad + 1
+    with pytest.raises(np.linalg.LinAlgError):
+        gpk.check(rc, "gpk_potrf")
+
+
+@pytest.mark.parametrize("nb", [128, 256, 512])
+def test_potrf_block_size_invariance(gpk, nb):
+    rng = np.random.RandomState(11)
+    N = 900
+    Q = rng.randn(N, N)
+    A = Q @ Q.T + N * np.eye(N)
+    gpk.set_option("nb", nb)
+    try:
+        Ain = A.copy()
+        assert gpk.lib().gpk_potrf(_ptr(Ain), N) == 0
+    finally:
+        gpk.set_option("nb", 256)
+    np.testing.assert_allclose(Ain @ Ain.T, A, rtol=1e-12, atol=1e-9)
+
+
+# ----------------------------------------------------------------------------- golden vectors (real reference)
+@pytest.mark.parametrize("case", golden_cases())
+def test_gpr_dropin_matches_reference_golden(gpk, case):
+    from gptest_amd import GPr
+
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    x, y, z, lh = g["x"], g["y"], g["z"], g["log_hyp"]
+    gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", x, y)
+    nlml = gp.compute_likelihood(lh)
+    assert isinstance(nlml, np.ndarray) and nlml.shape == (1, 1)
+    ref = float(g["nlml"].flat[0])
+    assert abs(nlml[0, 0] - ref) <= RTOL * max(1.0, abs(ref))
+    fz, cov = gp.compute_prediction(z)
+    assert fz.shape == (len(z),) and cov.shape == (len(z),)
+    np.testing.assert_allclose(fz, g["fz"], rtol=RTOL, atol=RTOL * np.abs(g["fz"]).max())
+    np.testing.assert_allclose(cov, g["cov_fz"], rtol=0, atol=RTOL * float(g["sf2"]))
+    np.testing.assert_allclose(gp.covFun.M, g["M"])
+    assert gp.covFun.sf2 == g["sf2"] and gp.covFun.sn2 == g["sn2"]
+    if "Kxx" in g.files:
+        np.testing.assert_allclose(gp.covFun.compute_Kxx_matrix(), g["Kxx"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(gp.covFun.compute_Kxz_matrix(z), g["Kxz"], rtol=1e-12, atol=1e-14)
+        M = g["M"]
+        xs = (x.reshape(len(x), -1) / M)
+        zs = (z.reshape(len(z), -1) / M)
+        np.testing.assert_allclose(GPr.squared_distance(xs, zs), g["sqdist_xz"], rtol=0, atol=1e-13 * max(1.0, g["sqdist_xz"].max()))
+
+
+def test_flat_and_column_inputs_agree(gpk):
+    """(N,) and (N,1) inputs are the same problem (GPr.py:5-6 reshapes both)."""
+    from gptest_amd import GPr
+
+    rng = np.random.RandomState(5)
+    x = rng.rand(60)
+    y = np.sin(5 * x)
+    z = rng.rand(9)
+    lh = np.log([0.3, 1.0, 0.1])
+    a = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", x, y)
+    b = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", x.reshape(-1, 1), y)
+    assert a.compute_likelihood(lh)[0, 0] == b.compute_likelihood(lh)[0, 0]
+    fa, ca = a.compute_prediction(z)
+    fb, cb = b.compute_prediction(z.reshape(-1, 1))
+    np.testing.assert_array_equal(fa, fb)
+    np.testing.assert_array_equal(ca, cb)
+
+
+def test_likelihood_uses_argument_not_constructor_hyp(gpk):
+    """GPr.py:59: compute_likelihood(hyp) builds a fresh covariance from ``hyp``."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+
+    X, y, Z, lh = orc.synthetic_problem(200, 2, 10)
+    other = lh + 0.3
+    gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", X, y)
+    got = gp.compute_likelihood(other)[0, 0]
+    want = float(orc.compute_likelihood_verbatim(other, X, y).flat[0])
+    assert abs(got - want) <= RTOL * abs(want)
+    # and prediction still uses the constructor's hyper-parameters
+    fz, _ = gp.compute_prediction(Z)
+    fo, _ = orc.compute_prediction_verbatim(lh, X, y, Z)
+    np.testing.assert_allclose(fz, fo, rtol=RTOL, atol=RTOL)
+
+
+# ----------------------------------------------------------------------------- oracle parity on seeded inputs
+@pytest.mark.parametrize("N,d,M", [(512, 1, 100), (1000, 4, 200), (2048, 8, 256), (4096, 4, 1024)])
+def test_posterior_matches_oracle(gpk, N, d, M):
+    """BASELINE configs 1-2 (+ intermediates): verbatim-cost oracle up to N=1000, efficient beyond."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+
+    X, y, Z, lh = orc.synthetic_problem(N, d, M)
+    gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", X, y)
+    nlml = gp.compute_likelihood(lh)[0, 0]
+    fz, cov = gp.compute_prediction(Z)
+    if N <= 1000:
+        nl_o, fz_o, cov_o = orc.posterior_verbatim(lh, X, y, Z)
+    else:
+        nl_o, fz_o, cov_o = orc.posterior_efficient(lh, X, y, Z)
+    assert abs(nlml - nl_o) <= RTOL * abs(nl_o)
+    np.testing.assert_allclose(fz, fz_o, rtol=RTOL, atol=RTOL * np.abs(fz_o).max())
+    np.testing.assert_allclose(cov, cov_o, rtol=0, atol=RTOL * np.exp(lh[d]) ** 2)
+    assert np.all(cov > -1e-9)  # np.sqrt(cov_y) must be real (GP_regression_demo.py:52-53)
+
+
+def test_solve_and_kmatvec_roundtrip(gpk):
+    """K^-1 (K v) == v and L^-1 b against the oracle's Cholesky (N not a tile multiple)."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+
+    X, y, _, lh = orc.synthetic_problem(700, 3, 4)
+    h, _ = GPr.fit_handle(X, y, lh, keep_k=True)
+    rng = np.random.RandomState(0)
+    V = np.ascontiguousarray(rng.randn(700, 3))
+    KV = np.empty_like(V)
+    assert gpk.lib().gpk_kmatvec(h.ptr, _ptr(V), 3, _ptr(KV)) == 0
+    K = orc.kxx(lh, X)
+    np.testing.assert_allclose(KV, K @ V, rtol=1e-11, atol=1e-11)
+    back = np.empty_like(V)
+    assert gpk.lib().gpk_solve(h.ptr, _ptr(KV), 3, _ptr(back)) == 0
+    np.testing.assert_allclose(back, V, rtol=1e-7, atol=1e-7)
+    low = np.empty_like(V)
+    assert gpk.lib().gpk_solve_lower(h.ptr, _ptr(V), 3, _ptr(low)) == 0
+    L = np.linalg.cholesky(K)
+    np.testing.assert_allclose(low, np.linalg.solve(L, V), rtol=1e-9, atol=1e-9)
+    Lg = np.empty((700, 700))
+    assert gpk.lib().gpk_model_get_L(h.ptr, _ptr(Lg)) == 0
+    np.testing.assert_allclose(Lg, L, rtol=1e-10, atol=1e-10)
+    idx = np.array([5, 699, 0, 123], dtype=np.int64)
+    G = np.empty((4, 4))
+    assert gpk.lib().gpk_kgather(h.ptr, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), 4, _ptr(G)) == 0
+    np.testing.assert_allclose(G, K[np.ix_(idx, idx)], rtol=1e-12)
+
+
+def test_not_positive_definite_fit_raises(gpk):
+    """Duplicate points with zero noise -> singular K -> LinAlgError (the only error GPpref.py:133 handles)."""
+    from gptest_amd import GPr
+
+    x = np.r_[np.linspace(0, 1, 40), np.linspace(0, 1, 40)]
+    lh = np.array([np.log(0.5), 0.0, -np.inf])
+    with pytest.raises(np.linalg.LinAlgError):
+        GPr.fit_handle(x, np.zeros(80), lh, jitter=0.0)
+    # with the reference's retry jitter it succeeds
+    h, _ = GPr.fit_handle(x, np.zeros(80), lh, jitter=1e-6)
+    assert h.ptr
+
+
+# ----------------------------------------------------------------------------- full-size properties (C3)
+def test_full_size_properties_c3(gpk):
+    """N=16384, d=8 (BASELINE config 3): size-independent properties instead of an O(N^3) CPU oracle.
+    * nlml is invariant to the panel width (different summation orders, same mathematics);
+    * the posterior mean at the training inputs reproduces K (K+sn2 I)^-1 y: checked through the
+      identity  y - mean_train = sn2 * alpha  with alpha = K^-1 y from gpk_solve;
+    * variances are in [0, sf2]."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+
+    N, d, M = 16384, 8, 1024
+    X, y, Z, lh = orc.synthetic_problem(N, d, M)
+    h, nlml = GPr.fit_handle(X, y, lh)
+    alpha = np.empty((N, 1))
+    assert gpk.lib().gpk_solve(h.ptr, _ptr(np.ascontiguousarray(y.reshape(N, 1))), 1, _ptr(alpha)) == 0
+    sub = np.ascontiguousarray(X[:1024])
+    mean = np.empty(1024)
+    var = np.empty(1024)
+    assert gpk.lib().gpk_predict(h.ptr, _ptr(sub), 1024, _ptr(mean), _ptr(var)) == 0
+    sn2 = np.exp(lh[-1]) ** 2
+    sf2 = np.exp(lh[-2]) ** 2
+    np.testing.assert_allclose(y[:1024] - mean, sn2 * alpha[:1024, 0], rtol=0, atol=1e-8)
+    assert np.all(var > -1e-9) and np.all(var <= sf2 + 1e-12)
+    del h
+    gpk.set_option("nb", 512)
+    try:
+        _, nlml2 = GPr.fit_handle(X, y, lh)
+    finally:
+        gpk.set_option("nb", 256)
+    assert abs(nlml - nlml2) <= 1e-9 * abs(nlml)
