@@ -60,6 +60,9 @@ def _bind(l):
         "gpk_test_potf2_128": (i, [dp, dp, dp]),
         "gpk_bench_gemm_nt": (i, [i, i, i, i, i, i, dp]),
         "gpk_bench_mfma_peak": (i, [i, dp]),
+        "gpk_bench_mfma_peak2": (i, [i, i, i, dp]),
+        "gpk_bench_mfma_mix": (i, [i, i, i, dp]),
+        "gpk_bench_leaf": (i, [i, i, dp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(l, name)  # AttributeError here = header/library mismatch

@@ -32,11 +32,51 @@ int gpk_init(int device) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return gpk_set_err(-2, "gpk_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
                        prop.gcnArchName);
+  // Stream layout.  The leaf kernel needs 132 KiB of LDS, i.e. a CU with no trailing-update
+  // workgroup resident; behind a queue of thousands of 72 KiB GEMM workgroups it would starve.
+  // So one CU is reserved (CU mask) for the leaf stream and the GEMM streams get the other 255.
+  const int ncu = prop.multiProcessorCount;
+  const char* env_res = getenv("GPK_RESERVE_CU");
+  const bool want_reserve = !(env_res && env_res[0] == '0') && ncu >= 64;
+  bool masked = false;
+  if (want_reserve) {
+    const int words = (ncu + 31) / 32;
+    std::vector<uint32_t> m_all(words, 0u), m_leaf(words, 0u);
+    for (int c = 0; c < ncu; ++c) m_all[c / 32] |= (1u << (c % 32));
+    const int r = ncu - 1;
+    m_all[r / 32] &= ~(1u << (r % 32));
+    m_leaf[r / 32] |= (1u << (r % 32));
+    hipError_t e1 = hipExtStreamCreateWithCUMask(&G.s_main, words, m_all.data());
+    hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&G.s_panel, words, m_all.data()) : e1;
+    hipError_t e3 = e2 == hipSuccess ? hipExtStreamCreateWithCUMask(&G.s_leaf, words, m_leaf.data()) : e2;
+    masked = (e3 == hipSuccess);
+    if (!masked) {
+      (void)hipGetLastError();
+      if (G.s_main) (void)hipStreamDestroy(G.s_main);
+      if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
+  if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
+  for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
+  G.ev_ring.clear();
+  for (hipEvent_t e : G.ev_pool) (void)hipEventDestroy(e);
+  G.ev_pool.clear();
+      G.s_main = G.s_panel = G.s_leaf = nullptr;
+    }
+  }
   int lo = 0, hi = 0;
   GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  GPK_HIP(hipStreamCreateWithPriority(&G.s_main, hipStreamNonBlocking, lo));
-  GPK_HIP(hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, hi));
+  if (!masked) {
+    GPK_HIP(hipStreamCreateWithPriority(&G.s_main, hipStreamNonBlocking, lo));
+    GPK_HIP(hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, hi));
+    G.s_leaf = G.s_panel;
+  }
+  G.cu_reserved = masked;
+  G.ncu = masked ? ncu - 1 : ncu;
   GPK_HIP(hipStreamCreateWithPriority(&G.s_comm, hipStreamNonBlocking, hi));
+  for (int i = 0; i < 64; ++i) {
+    hipEvent_t e;
+    GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    G.ev_ring.push_back(e);
+  }
   G.device = device;
   G.inited = true;
   return 0;
@@ -53,9 +93,14 @@ void gpk_shutdown(void) {
   for (hipEvent_t e : G.ev_free) (void)hipEventDestroy(e);
   G.ev_free.clear();
   if (G.s_main) (void)hipStreamDestroy(G.s_main);
+  if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
   if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
+  for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
+  G.ev_ring.clear();
+  for (hipEvent_t e : G.ev_pool) (void)hipEventDestroy(e);
+  G.ev_pool.clear();
   if (G.s_comm) (void)hipStreamDestroy(G.s_comm);
-  G.s_main = G.s_panel = G.s_comm = nullptr;
+  G.s_main = G.s_panel = G.s_comm = G.s_leaf = nullptr;
   G.inited = false;
 }
 
@@ -75,6 +120,13 @@ int gpk_set_option(const char* key, double value) {
     G.nb = nb;
   } else if (k == "lookahead") {
     G.lookahead = (int)value;
+  } else if (k == "gemm_variant") {
+    extern int g_gemm_variant;
+    g_gemm_variant = (int)value;
+  } else if (k == "use_pp") {
+    G.use_pp = (int)value;
+  } else if (k == "pp_min_tiles") {
+    G.pp_min_tiles = (int)value;
   } else if (k == "timing") {
     G.timing = (int)value;
     if (!G.timing) timers_reset();
@@ -89,6 +141,7 @@ double gpk_get_option(const char* key) {
   if (k == "lookahead") return G.lookahead;
   if (k == "timing") return G.timing;
   if (k == "pool_bytes") return (double)G.pool_bytes;
+  if (k == "cu_reserved") return G.cu_reserved ? 1.0 : 0.0;
   return NAN;
 }
 
@@ -451,7 +504,7 @@ int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, 
     GemmNT g{};
     g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
     g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
-    rc = launch_gemm_nt(g, tile == 128, s);
+    rc = (tile == 1) ? launch_gemm_nt_pp(g, G.ncu, s) : launch_gemm_nt(g, tile == 128, s);
     if (rc) break;
     if (hipMemcpyAsync(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
     if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "test_gemm: %s", hipGetErrorString(hipGetLastError())); break; }
@@ -475,7 +528,7 @@ int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out) {
   do {
     if (hipMemcpyAsync(dA, A, 128 * 128 * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
     if (hipMemsetAsync(dinfo, 0, 16, s) != hipSuccess) { rc = gpk_set_err(-2, "memset failed"); break; }
-    rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, 128, s);
+    rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, 0, s);
     if (rc) break;
     if (hipMemcpyAsync(L_out, dL, 128 * 128 * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
     if (hipMemcpyAsync(Dinv_out, dD, 128 * 128 * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
@@ -494,16 +547,56 @@ int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out) {
 
 // ---------------------------------------------------------------- micro-benchmarks
 typedef double d4_t __attribute__((ext_vector_type(4)));
+template <int NACC>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters, double seed) {
+  d4_t acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (d4_t){0, 0, 0, 0};
+  double a = seed + threadIdx.x * 1e-3 * seed, b = seed - threadIdx.x * 1e-3 * seed;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)  // inline asm with "+v": accumulators stay in VGPRs, no AGPR copies
+      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 7 && threadIdx.x == 0) {  // shader clock = d(memtime)/d(memrealtime) x 100 MHz
+    reinterpret_cast<unsigned long long*>(out)[(size_t)gridDim.x * blockDim.x] = c1 - c0;
+    reinterpret_cast<unsigned long long*>(out)[(size_t)gridDim.x * blockDim.x + 1] = r1 - r0;
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// issue-pacing experiments: what between two f64 MFMAs lets the matrix pipe run closer to 64 cycles/MFMA?
+template <int MODE>
+__global__ __launch_bounds__(256) void mfma_mix_kernel(double* out, int iters, double seed) {
+  __shared__ double sh[1024];
   d4_t acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = (d4_t){0, 0, 0, 0};
-  double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+  sh[threadIdx.x] = seed + threadIdx.x;
+  sh[threadIdx.x + 256] = seed - threadIdx.x;
+  __syncthreads();
+  double a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = seed + threadIdx.x * 1e-3 * (i + 1); b[i] = seed - threadIdx.x * 1e-3 * (i + 1); }
+  const double* p = sh + (threadIdx.x & 63);
+  double dummy = 0;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < 8; ++i) {
+      if (MODE == 1) { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i], acc[i], 0, 0, 0); }
+      else if (MODE == 2) { double t = p[(i * 64 + (it & 1) * 512) & 1023]; acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[i], 0, 0, 0); dummy += t; }
+      else if (MODE == 3) { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[i], 0, 0, 0); asm volatile("s_nop 7\n\ts_nop 7"); }
+            else if (MODE == 5) { double t0 = p[(i * 64) & 1023]; double t1 = p[(i * 64 + 32) & 1023]; acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, t1, acc[i], 0, 0, 0); }
+      else { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[i], 0, 0, 0); }
+    }
   }
-  double s = 0;
+  double s = dummy;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -511,28 +604,112 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters, 
 
 extern "C" {
 
-int gpk_bench_mfma_peak(int iters, double* tflops_out) {
+int gpk_bench_mfma_mix(int mode, int waves_per_simd, int iters, double* tflops_out) {
   GPK_TRY(rt_require());
   hipStream_t s = G.s_main;
-  const int blocks = 256 * 2;  // 2 workgroups of 4 waves per CU
+  const int blocks = 256 * waves_per_simd;
   double* d = nullptr;
   GPK_TRY(dev_alloc_t(&d, (size_t)blocks * 256));
   hipEvent_t e0, e1;
   GPK_HIP(hipEventCreate(&e0));
   GPK_HIP(hipEventCreate(&e1));
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, d, iters / 10 + 1, 0.5);
+  auto go = [&](int n) {
+    switch (mode) {
+      case 1: hipLaunchKernelGGL(mfma_mix_kernel<1>, dim3(blocks), dim3(256), 0, s, d, n, 0.5); break;
+      case 2: hipLaunchKernelGGL(mfma_mix_kernel<2>, dim3(blocks), dim3(256), 0, s, d, n, 0.5); break;
+      case 3: hipLaunchKernelGGL(mfma_mix_kernel<3>, dim3(blocks), dim3(256), 0, s, d, n, 0.5); break;
+      case 5: hipLaunchKernelGGL(mfma_mix_kernel<5>, dim3(blocks), dim3(256), 0, s, d, n, 0.5); break;
+      default: hipLaunchKernelGGL(mfma_mix_kernel<0>, dim3(blocks), dim3(256), 0, s, d, n, 0.5); break;
+    }
+  };
+  go(iters / 10 + 1);
   GPK_HIP(hipEventRecord(e0, s));
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, d, iters, 0.5);
+  go(iters);
   GPK_HIP(hipEventRecord(e1, s));
   GPK_HIP(hipEventSynchronize(e1));
   float ms = 0;
   GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
-  const double flops = (double)blocks * 4 /*waves*/ * (double)iters * 8 * 2048.0;
-  if (tflops_out) *tflops_out = flops / (ms * 1e-3) / 1e12;
+  if (tflops_out) *tflops_out = (double)blocks * 4 * (double)iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   dev_free(d, (size_t)blocks * 256 * 8);
   return 0;
+}
+
+// nacc in {1,2,4,8,16,32} independent accumulators per wave; waves_per_simd in {1,2,3,4}
+int gpk_bench_mfma_peak2(int nacc, int waves_per_simd, int iters, double* tflops_out) {
+  GPK_TRY(rt_require());
+  const double seed = (iters < 0) ? 0.0 : 0.5;  // negative iters: all-zero operands (lowest switching power)
+  if (iters < 0) iters = -iters;
+  hipStream_t s = G.s_main;
+  const int blocks = 256 * waves_per_simd;
+  double* d = nullptr;
+  GPK_TRY(dev_alloc_t(&d, (size_t)blocks * 256 + 2));
+  hipEvent_t e0, e1;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  auto go = [&](int n) {
+    switch (nacc) {
+      case 1: hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
+      case 2: hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
+      case 4: hipLaunchKernelGGL(mfma_peak_kernel<4>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
+      case 8: hipLaunchKernelGGL(mfma_peak_kernel<8>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
+      case 16: hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
+      default: hipLaunchKernelGGL(mfma_peak_kernel<32>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
+    }
+  };
+  go(iters / 10 + 1);
+  GPK_HIP(hipEventRecord(e0, s));
+  go(iters);
+  GPK_HIP(hipEventRecord(e1, s));
+  GPK_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * 4 * (double)iters * (nacc > 16 ? 32 : nacc) * 2048.0;
+  if (tflops_out) *tflops_out = flops / (ms * 1e-3) / 1e12;
+  unsigned long long clk[2] = {0, 0};
+  GPK_HIP(hipMemcpy(clk, d + (size_t)blocks * 256, 16, hipMemcpyDeviceToHost));
+  if (tflops_out && clk[1]) tflops_out[1] = (double)clk[0] / (double)clk[1] * 0.1;  // GHz
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dev_free(d, (size_t)blocks * 256 * 8);
+  return 0;
+}
+
+int gpk_bench_mfma_peak(int iters, double* tflops_out) { return gpk_bench_mfma_peak2(8, 2, iters, tflops_out); }
+
+int gpk_bench_leaf(int dbg_skip, int reps, double* us_out) {
+  GPK_TRY(rt_require());
+  hipStream_t s = G.s_main;
+  double *dA = nullptr, *dL = nullptr, *dD = nullptr;
+  int* dinfo = nullptr;
+  GPK_TRY(dev_alloc_t(&dA, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dL, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dD, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dinfo, 4));
+  std::vector<double> h(128 * 128);
+  for (int i = 0; i < 128; ++i)
+    for (int j = 0; j < 128; ++j) h[i * 128 + j] = (i == j ? 4.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
+  GPK_HIP(hipMemcpyAsync(dA, h.data(), 128 * 128 * 8, hipMemcpyHostToDevice, s));
+  GPK_HIP(hipMemsetAsync(dinfo, 0, 16, s));
+  int rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg_skip, s);
+  hipEvent_t e0, e1;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  GPK_HIP(hipEventRecord(e0, s));
+  for (int r = 0; r < reps && !rc; ++r) rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg_skip, s);
+  GPK_HIP(hipEventRecord(e1, s));
+  GPK_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (us_out) *us_out = 1e3 * ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dev_free(dA, 128 * 128 * 8);
+  dev_free(dL, 128 * 128 * 8);
+  dev_free(dD, 128 * 128 * 8);
+  dev_free(dinfo, 16);
+  return rc;
 }
 
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out) {
@@ -551,18 +728,24 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
   GPK_TRY(launch_fill(dC, (size_t)m * n, 1.0, s));
   GemmNT g{};
   g.A = dA; g.lda = k; g.B = lower ? dA : dB; g.ldb = k; g.C = dC; g.ldc = n;
-  g.m = m; g.n = n; g.k = k; g.sub = 1; g.lower = lower;
-  int rc = launch_gemm_nt(g, tile == 128, s);
+  g.m = m; g.n = n; g.k = k; g.sub = 1; g.lower = lower & 1; g.dbg = lower >> 1;
+  extern int g_gemm_variant;
+  const int saved_variant = g_gemm_variant;
+  if (tile == 4) g_gemm_variant = 4;
+  if (tile == 8) g_gemm_variant = 8;
+  auto go = [&]() { return (tile == 1) ? launch_gemm_nt_pp(g, G.ncu, s) : launch_gemm_nt(g, tile != 64, s); };
+  int rc = go();
   hipEvent_t e0, e1;
   GPK_HIP(hipEventCreate(&e0));
   GPK_HIP(hipEventCreate(&e1));
   GPK_HIP(hipEventRecord(e0, s));
-  for (int r = 0; r < reps && !rc; ++r) rc = launch_gemm_nt(g, tile == 128, s);
+  for (int r = 0; r < reps && !rc; ++r) rc = go();
   GPK_HIP(hipEventRecord(e1, s));
   GPK_HIP(hipEventSynchronize(e1));
   float ms = 0;
   GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
   if (ms_out) *ms_out = ms / reps;
+  g_gemm_variant = saved_variant;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   dev_free(dA, (size_t)m * k * 8);

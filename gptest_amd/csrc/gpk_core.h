@@ -16,18 +16,26 @@ struct Runtime {
   bool inited = false;
   int device = 0;
   hipStream_t s_main = nullptr, s_panel = nullptr, s_comm = nullptr;
+  hipStream_t s_leaf = nullptr;   // CU-masked stream owning one reserved CU for the 1-workgroup leaf kernels
+  bool cu_reserved = false;
+  std::vector<hipEvent_t> ev_ring;
+  size_t ev_ring_pos = 0;
   std::map<size_t, std::vector<void*>> pool;
   size_t pool_bytes = 0;
   // options
   int nb = 256;
   int lookahead = 1;
   int timing = 0;
+  int use_pp = 0;        // experimental persistent pipelined GEMM (k_gemm_pp.hip); slower than the 8-wave kernel, off
+  int pp_min_tiles = 384; // below this many 128x128 tiles the plain kernel (2 workgroups/CU) is used
+  int ncu = 256;         // CUs available to the GEMM streams
   int small_tile_rows = 4096;  // GEMMs with n == 128 use the 64x64 tile below this many rows... (see potrf)
   // comm
   int rank = 0, nranks = 1;
   void* nccl = nullptr;
   std::map<std::string, StageTimer> timers;
   std::vector<hipEvent_t> ev_free;
+  std::vector<hipEvent_t> ev_pool;  // dependency events of the look-ahead schedule
 };
 extern Runtime G;
 

@@ -21,6 +21,15 @@ int rt_require() {
   return 0;
 }
 
+int launch_gemm_auto(const GemmNT& g, hipStream_t s) {
+  if (G.use_pp && g.sub && g.cyc_P == 0 && (g.k == 256 || g.k == 512) && g.m % 128 == 0 && g.n % 128 == 0) {
+    const long ntm = g.m / 128, ntn = g.n / 128;
+    const long nt = g.lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
+    if (nt >= G.pp_min_tiles) return launch_gemm_nt_pp(g, G.ncu, s);
+  }
+  return launch_gemm_nt(g, true, s);
+}
+
 // ------------------------------------------------------------------ allocator
 int dev_alloc(void** p, size_t bytes) {
   if (bytes == 0) bytes = 256;
@@ -194,6 +203,29 @@ int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m) {
 // sub-panels inside a panel.  L goes to its own panel-packed storage (panel p =
 // rows c0.. x w, ld = w): compact operands for every later kernel and no in-place hazard
 // in the panel solve.  Replaces np.linalg.cholesky (GPr.py:62, GPpref.py:128).
+static hipEvent_t ring_event() {
+  hipEvent_t e = G.ev_ring[G.ev_ring_pos % G.ev_ring.size()];
+  G.ev_ring_pos++;
+  return e;
+}
+
+// The 1-workgroup leaf goes to the stream that owns the reserved CU; `s` is fenced around it.
+static int launch_leaf(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, hipStream_t s) {
+  hipStream_t sl = (G.cu_reserved && G.s_leaf) ? G.s_leaf : s;
+  if (sl != s) {
+    hipEvent_t e = ring_event();
+    GPK_HIP(hipEventRecord(e, s));
+    GPK_HIP(hipStreamWaitEvent(sl, e, 0));
+  }
+  GPK_TRY(launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, sl));
+  if (sl != s) {
+    hipEvent_t e = ring_event();
+    GPK_HIP(hipEventRecord(e, sl));
+    GPK_HIP(hipStreamWaitEvent(s, e, 0));
+  }
+  return 0;
+}
+
 static int factor_panel(gpk_model* m, int p, hipStream_t s) {
   const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
   double* Lp = m->Lpanel(p);
@@ -212,7 +244,7 @@ static int factor_panel(gpk_model* m, int p, hipStream_t s) {
       GPK_TRY(launch_gemm_nt(g, false, s));
     }
     double* Dt = m->dDinv + (long)(cs / 128) * 128 * 128;
-    GPK_TRY(launch_potf2_trtri_128(Acol, np_, Lp + (long)ro * w + sb * 128, w, Dt, m->dinfo, cs, 128, s));
+    GPK_TRY(launch_leaf(Acol, np_, Lp + (long)ro * w + sb * 128, w, Dt, m->dinfo, cs, s));
     if (h - ro - 128 > 0) {
       // L[cs+128:, sub-panel] = A[cs+128:, cs:cs+128] * Dinv^T
       GemmNT g{};
@@ -226,33 +258,78 @@ static int factor_panel(gpk_model* m, int p, hipStream_t s) {
   return 0;
 }
 
-static int trailing_update(gpk_model* m, int p, int first_tile, int ntiles, hipStream_t s) {
-  // A[c0+w:, c0+w:] (lower tiles) -= Lp[w:, :] * Lp[w:, :]^T, restricted to row/col tiles >= first_tile
+// A[r0g:, c0g : c0g+ncols] -= Lp[(r0g-c0p):, :] * Lp[(c0g-c0p) : +ncols, :]^T   (rows r0g.., global indices)
+// lower = 1: square region on the diagonal (r0g == c0g, ncols == rows), only tiles on/below it.
+static int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hipStream_t s) {
   const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
-  const int h = np_ - c0;
-  const int mm = h - w;
-  if (mm <= 0) return 0;
-  (void)first_tile; (void)ntiles;
+  const int rows = np_ - r0g;
+  if (rows <= 0 || ncols <= 0) return 0;
   double* Lp = m->Lpanel(p);
   GemmNT g{};
-  g.A = Lp + (long)w * w; g.lda = w;
-  g.B = g.A; g.ldb = w;
-  g.C = m->dK + (long)(c0 + w) * np_ + (c0 + w); g.ldc = np_;
-  g.m = mm; g.n = mm; g.k = w; g.sub = 1; g.lower = 1;
-  return launch_gemm_nt(g, true, s);
+  g.A = Lp + (long)(r0g - c0) * w; g.lda = w;
+  g.B = Lp + (long)(c0g - c0) * w; g.ldb = w;
+  g.C = m->dK + (long)r0g * np_ + c0g; g.ldc = np_;
+  g.m = rows; g.n = ncols; g.k = w; g.sub = 1; g.lower = lower;
+  return launch_gemm_auto(g, s);
 }
 
+static hipEvent_t ev_new() {
+  hipEvent_t e;
+  (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  return e;
+}
+
+// Right-looking with one panel of look-ahead: while the big SYRK of panel p runs on s_main, the
+// high-priority s_panel stream updates block column p+1 and factors panel p+1, so the latency-bound
+// leaf/panel kernels leave the critical path.
 int potrf_device(gpk_model* m) {
-  hipStream_t s = G.s_main;
-  GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, s));
-  for (int p = 0; p < m->nP; ++p) {
-    timer_begin("panel", s);
-    GPK_TRY(factor_panel(m, p, s));
-    timer_end("panel", s);
-    timer_begin("trailing", s);
-    GPK_TRY(trailing_update(m, p, 0, 0, s));
-    timer_end("trailing", s);
+  hipStream_t sm = G.s_main, sp = G.s_panel;
+  GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
+  const int nP = m->nP;
+  if (!G.lookahead || nP < 3) {
+    for (int p = 0; p < nP; ++p) {
+      timer_begin("panel", sm);
+      GPK_TRY(factor_panel(m, p, sm));
+      timer_end("panel", sm);
+      const int r0 = m->pc0[p] + m->pw[p];
+      timer_begin("trailing", sm);
+      GPK_TRY(panel_update(m, p, r0, r0, m->Npad - r0, 1, sm));
+      timer_end("trailing", sm);
+    }
+    return 0;
   }
+  if ((int)G.ev_pool.size() < 2 * nP + 2)
+    while ((int)G.ev_pool.size() < 2 * nP + 2) G.ev_pool.push_back(ev_new());
+  hipEvent_t* ev_panel = G.ev_pool.data();        // panel p factored (recorded on s_panel)
+  hipEvent_t* ev_trail = G.ev_pool.data() + nP;   // rest-update of step p done (recorded on s_main)
+  hipEvent_t ev_start = G.ev_pool[2 * nP];
+  // s_panel must not start before the K build queued on s_main has finished
+  GPK_HIP(hipEventRecord(ev_start, sm));
+  GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
+  GPK_TRY(factor_panel(m, 0, sp));
+  GPK_HIP(hipEventRecord(ev_panel[0], sp));
+  for (int p = 0; p < nP; ++p) {
+    const int r0 = m->pc0[p] + m->pw[p];             // first row/col of the trailing matrix
+    const int wn = (p + 1 < nP) ? m->pw[p + 1] : 0;  // width of the look-ahead block column
+    if (p + 1 < nP) {
+      // (a) s_panel: block column p+1 gets panel p's update, then panel p+1 is factored.
+      if (p > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[p - 1], 0));  // earlier updates of that column
+      GPK_TRY(panel_update(m, p, r0, r0, wn, 0, sp));
+      GPK_TRY(factor_panel(m, p + 1, sp));
+      GPK_HIP(hipEventRecord(ev_panel[p + 1], sp));
+    }
+    // (b) s_main: the rest of the trailing matrix (lower triangle starting after block column p+1)
+    GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
+    const int r1 = r0 + wn;
+    if (m->Npad - r1 > 0) {
+      timer_begin("trailing", sm);
+      GPK_TRY(panel_update(m, p, r1, r1, m->Npad - r1, 1, sm));
+      timer_end("trailing", sm);
+    }
+    GPK_HIP(hipEventRecord(ev_trail[p], sm));
+  }
+  // join: everything after potrf runs on s_main and needs the last panel
+  GPK_HIP(hipStreamWaitEvent(sm, ev_panel[nP - 1], 0));
   return 0;
 }
 
@@ -347,7 +424,7 @@ int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, 
       g.B = Lp + (long)w * w; g.ldb = w;
       g.C = dR + c0 + w; g.ldc = np_;
       g.m = Mpad; g.n = h - w; g.k = w; g.sub = 1;
-      GPK_TRY(launch_gemm_nt(g, true, s));
+      GPK_TRY(launch_gemm_auto(g, s));
     }
   }
   GPK_TRY(launch_row_stats(dV, np_, M, np_, m->dw, m->se.sf2, dmean, dvar, s));

@@ -134,6 +134,120 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
   }
 }
 
+int g_gemm_variant = 8;  // 8: 8-wave 128x128 kernel (default); 4: the 4-wave kernel
+
+// ---------------------------------------------------------------------------------------------
+// 8-wave variant of the 128x128 tile: wave tile 64x32 (4x2 MFMA tiles, 64 accumulator VGPRs), <=128
+// VGPRs per wave, two workgroups per CU = FOUR waves per SIMD.  Measured on MI355X with a pure
+// v_mfma_f64_16x16x4_f64 issue loop (gpk_bench_mfma_peak2): one wave per SIMD reaches 52% of the
+// matrix-pipe peak, two 69%, four 82% -- a single wave cannot issue f64 MFMAs back to back, so
+// occupancy, not instruction-level parallelism, is what fills the pipe.
+// sub mode: the accumulators START as C (loaded while the first K-slab is in flight) and A is
+// negated on its way into LDS, so the MFMA chain itself yields C - A*B^T and the epilogue is
+// store-only (no load -> subtract -> store dependency at the end of every tile).
+__global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
+  constexpr int BT = 128;
+  __shared__ double lds[2 * 2 * BT * LDS_LD];
+  double* As = lds;
+  double* Bs = lds + 2 * BT * LDS_LD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;  // 2 x 4 waves of 64 x 32
+
+  int ti, tj;
+  const int ntn = g.n / BT;
+  if (g.lower && g.cyc_P == 0) {
+    int id = blockIdx.x;
+    int t = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+    while (t * (t + 1) / 2 > id) --t;
+    while ((t + 1) * (t + 2) / 2 <= id) ++t;
+    ti = t;
+    tj = id - t * (t + 1) / 2;
+  } else {
+    ti = blockIdx.x / ntn;
+    tj = blockIdx.x % ntn;
+  }
+  long brow0;
+  if (g.cyc_P > 0) {
+    const int tpb = g.cyc_NB / BT;
+    long gcol = ((long)(tj / tpb + g.cyc_lg0) * g.cyc_P + g.cyc_r) * g.cyc_NB + (long)(tj % tpb) * BT;
+    if (g.lower && gcol > g.row_g0 + (long)ti * BT) return;
+    brow0 = gcol - g.brow_g0;
+  } else {
+    brow0 = (long)tj * BT;
+  }
+  const double* Ag = g.A + (long)ti * BT * g.lda;
+  const double* Bg = g.B + brow0 * g.ldb;
+  const int lrow = tid >> 3, lchk = (tid & 7) * 2;  // 64 rows x 8 chunks per pass
+  const int fr = lane & 15, fg = lane >> 4;
+  double* Cw = g.C + ((long)ti * BT + wm * 64) * g.ldc + (long)tj * BT + wn * 32;  // wave-uniform
+  const unsigned c_off = (unsigned)fg * (unsigned)g.ldc + (unsigned)fr;
+
+  d4 acc[4][2];
+  if (g.sub) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = (Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16)[c_off];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
+
+  d2 ra[2], rb[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      ra[p] = *reinterpret_cast<const d2*>(Ag + (long)(p * 64 + lrow) * g.lda + kt * BK + lchk);
+      rb[p] = *reinterpret_cast<const d2*>(Bg + (long)(p * 64 + lrow) * g.ldb + kt * BK + lchk);
+    }
+  };
+  const double sgn = g.sub ? -1.0 : 1.0;
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      d2 na = {sgn * ra[p].x, sgn * ra[p].y};
+      *reinterpret_cast<d2*>(As + (buf * BT + p * 64 + lrow) * LDS_LD + lchk) = na;
+      *reinterpret_cast<d2*>(Bs + (buf * BT + p * 64 + lrow) * LDS_LD + lchk) = rb[p];
+    }
+  };
+
+  const int nk = g.k / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const double* Ab = As + (buf * BT + wm * 64 + fr) * LDS_LD + fg;
+    const double* Bb = Bs + (buf * BT + wn * 32 + fr) * LDS_LD + fg;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = Ab[i * 16 * LDS_LD + kk];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bb[j * 16 * LDS_LD + kk];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) (Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16)[c_off] = acc[i][j][r];
+}
+
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
   const int BT = tile128 ? 128 : 64;
   if (g.m <= 0 || g.n <= 0) return 0;
@@ -149,7 +263,9 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
   } else {
     nblk = (long)ntm * ntn;
   }
-  if (tile128)
+  if (tile128 && g_gemm_variant == 8)
+    hipLaunchKernelGGL(gemm_nt8_kernel, dim3((unsigned)nblk), dim3(512), 0, s, g);
+  else if (tile128)
     hipLaunchKernelGGL(gemm_nt_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, g);
   else
     hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, g);

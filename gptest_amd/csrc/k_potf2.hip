@@ -1,24 +1,34 @@
-// Leaf of the blocked Cholesky: factor one 128x128 diagonal tile in LDS and invert
-// the triangular factor (the inverse turns every panel solve into an MFMA GEMM).
-// Replaces the unblocked interior of LAPACK potrf behind np.linalg.cholesky
-// (GPr.py:62, GPpref.py:128).
+// Leaf of the blocked Cholesky: factor one 128x128 diagonal tile and invert the triangular
+// factor (the inverse turns every panel solve into an MFMA GEMM).  Replaces the unblocked
+// interior of LAPACK potrf behind np.linalg.cholesky (GPr.py:62, GPpref.py:128).
 //
-// One workgroup of 1024 threads, the whole tile resident in LDS (128 x 129 doubles =
-// 129 KiB of the CU's 160 KiB; the odd row stride makes column walks conflict-free).
-//  1. square-root-free right-looking elimination, ONE barrier per column:
-//        S[i][k] -= S[i][j] * S[k][j] / S[j][j]      (j < k <= i)
-//     column j and the pivot are never written again after step j, so the scaling
-//     L[i][j] = S[i][j]/sqrt(S[j][j]) is applied once at the end.
-//  2. in-place triangular inverse by recursive doubling (block sizes 1,2,..,64):
-//        X21 = -X22 * (L21 * X11), intermediate product held in registers.
+// One workgroup of 1024 threads (16 waves) on one CU.
+//  1. Elimination with the WHOLE tile in registers: thread (i, kg) owns row i and the column
+//     pairs {16*q + 2*kg, +1 | q = 0..7} (cyclic pairs: balanced until the last columns, and
+//     the published column is read back as 16-byte pairs).  Per column j the owners publish
+//     column j and 1/pivot into a double-buffered LDS vector, ONE barrier, then every thread
+//     applies the rank-1 update to its registers with no per-lane predicate: the full symmetric
+//     tile is updated, the lower triangle is bit-for-bit what a masked update would give.
+//     Square-root-free: column j and pivot j are final after step j, L = S*diag(1/sqrt(piv))
+//     is applied once at the end.
+//  2. In-place inverse of L in LDS (128 x 129 doubles, odd stride = conflict-free column
+//     walks) by recursive doubling, X21 = -X22*(L21*X11): block sizes 1..8 with scalar FMAs,
+//     16/32/64 with v_mfma_f64_16x16x4_f64 reading its fragments straight from the tile.
 #include "gpk_internal.h"
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
 #define PLD 129
+#define CBLD 132  // published column: 128 values + 1/pivot at [128], padded to a multiple of 2
 
 __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __restrict__ A, long lda,
                                                                double* __restrict__ L, long ldl,
-                                                               double* __restrict__ Dinv, int* info, int col0) {
-  __shared__ double S[128 * PLD];
+                                                               double* __restrict__ Dinv, int* info, int col0,
+                                                               int dbg_skip) {
+  __shared__ __attribute__((aligned(16))) double S[128 * PLD + 2 * CBLD + 128];
+  double* colbuf = S + 128 * PLD;       // [2][CBLD]; 128*129 and CBLD are even -> 16-byte aligned pair reads
+  double* pivbuf = colbuf + 2 * CBLD;   // [128] pivots
   const int tid = threadIdx.x;
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int i = e >> 7, j = e & 127;
@@ -26,20 +36,65 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   }
   __syncthreads();
 
-  const int i = tid & 127, kg = tid >> 7;
+  const int i = tid & 127;
+  const int kg = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform -> scalar branches below
+  double a[8][2];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    a[q][0] = S[i * PLD + 16 * q + 2 * kg];
+    a[q][1] = S[i * PLD + 16 * q + 2 * kg + 1];
+  }
   int fail = 0;
-  for (int j = 0; j < 128; ++j) {
-    const double ajj = S[j * PLD + j];
-    if (!(ajj > 0.0) || !(ajj < 1.0e300)) {  // also catches NaN / Inf; wave- and block-uniform
-      fail = j + 1;
-      break;
+#pragma unroll
+  for (int jq = 0; jq < 8; ++jq) {
+    if (dbg_skip & 1) break;
+#pragma nounroll
+    for (int jkg = 0; jkg < 8; ++jkg) {  // NOT unrolled: the fully unrolled body overflows the instruction cache
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {
+        const int j = 16 * jq + 2 * jkg + jh;
+        double* cb = colbuf + (j & 1) * CBLD;
+        if (kg == jkg) {
+          const double v = a[jq][jh];
+          cb[i] = v;
+          if (i == j) {
+            const bool ok = (v > 1.0e-300) && (v < 1.0e300);
+            // reciprocal on the critical path of every column: v_rcp_f64 + two Newton steps (~1 ulp)
+            double rcp = __builtin_amdgcn_rcp(v);
+            rcp = rcp * (2.0 - v * rcp);
+            rcp = rcp * (2.0 - v * rcp);
+            cb[128] = ok ? rcp : -1.0;  // non-positive / NaN / Inf pivot -> flagged to everyone
+            pivbuf[j] = v;
+          }
+        }
+        __syncthreads();
+        // issue every LDS read of this step back to back (one latency, not three), then test the pivot
+        const double rinv = cb[128];
+        const double ci = cb[i];
+        d2 cq[8];
+#pragma unroll
+        for (int q = jq; q < 8; ++q) cq[q] = *reinterpret_cast<const d2*>(cb + 16 * q + 2 * kg);
+        if (!(rinv > 0.0)) {  // block-uniform
+          fail = j + 1;
+          break;
+        }
+        const double lij = ci * rinv;
+        // columns of this thread in block jq that are right of column j (wave-uniform tests)
+        if (kg > jkg) {
+          a[jq][0] -= lij * cq[jq].x;
+          a[jq][1] -= lij * cq[jq].y;
+        } else if (kg == jkg && jh == 0) {
+          a[jq][1] -= lij * cq[jq].y;  // column j+1 is the second half of this thread's own pair
+        }
+#pragma unroll
+        for (int q = jq + 1; q < 8; ++q) {
+          a[q][0] -= lij * cq[q].x;
+          a[q][1] -= lij * cq[q].y;
+        }
+      }
+      if (fail) break;
     }
-    const double r = 1.0 / ajj;
-    if (i > j) {
-      const double lij = S[i * PLD + j];
-      for (int k = j + 1 + kg; k <= i; k += 8) S[i * PLD + k] -= lij * (S[k * PLD + j] * r);
-    }
-    __syncthreads();
+    if (fail) break;
   }
   __syncthreads();
   if (fail) {
@@ -53,76 +108,105 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
     }
     return;
   }
-
-  // ---- scale columns: L = S * diag(1/sqrt(pivot))
-  double v[16];
+  // ---- scale: L[i][k] = a / sqrt(piv_k), L[k][k] = sqrt(piv_k), zero above; back to LDS
+  double* isq = colbuf;  // [128] 1/sqrt(piv), computed once per column
+  if (tid < 128) {
+    const double dk = sqrt(pivbuf[tid]);
+    pivbuf[tid] = dk;
+    isq[tid] = 1.0 / dk;
+  }
+  __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int e = tid + 1024 * q;
-    const int ii = e >> 7, jj = e & 127;
-    double x = 0.0;
-    if (jj <= ii) {
-      const double dj = sqrt(S[jj * PLD + jj]);
-      x = (ii == jj) ? dj : S[ii * PLD + jj] / dj;
+  for (int q = 0; q < 8; ++q) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = 16 * q + 2 * kg + h;
+      double x = 0.0;
+      if (k < i) x = a[q][h] * isq[k];
+      if (k == i) x = pivbuf[k];
+      S[i * PLD + k] = x;
     }
-    v[q] = x;
-    L[(long)ii * ldl + jj] = x;
   }
   __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int e = tid + 1024 * q;
-    S[(e >> 7) * PLD + (e & 127)] = v[q];
+  for (int e = tid; e < 128 * 128; e += 1024) {
+    const int ii = e >> 7, jj = e & 127;
+    L[(long)ii * ldl + jj] = S[ii * PLD + jj];
   }
   __syncthreads();
-
-  // ---- in-place inverse of the lower-triangular factor
   if (tid < 128) S[tid * PLD + tid] = 1.0 / S[tid * PLD + tid];
   __syncthreads();
-  for (int lb = 0; lb < 7; ++lb) {  // b = 1 << lb
+
+  // ---- in-place inverse, block sizes 1, 2, 4, 8: scalar
+  const int nlev_scalar = (dbg_skip & 2) ? 0 : 4;
+  for (int lb = 0; lb < nlev_scalar; ++lb) {
     const int b = 1 << lb;
-    const int nel = 64 * b;  // (64/b pairs) * b*b elements
-    double t[4];
-    int rr[4], cc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = tid + 1024 * q;
-      t[q] = 0.0;
-      rr[q] = -1;
-      cc[q] = 0;
-      if (e < nel) {
-        const int pair = e >> (2 * lb);
-        const int rem = e & (b * b - 1);
-        const int ii = rem >> lb, c = rem & (b - 1);
-        const int r0 = 2 * b * pair;
-        const int row = r0 + b + ii;
-        double sum = 0.0;
-        for (int k = c; k < b; ++k) sum += S[row * PLD + r0 + k] * S[(r0 + k) * PLD + r0 + c];
-        t[q] = sum;
-        rr[q] = row;
-        cc[q] = r0 + c;
-      }
+    const int nel = 64 * b;  // (64/b pairs) * b*b elements, <= 512
+    double t = 0.0;
+    int row = -1, col = 0;
+    if (tid < nel) {
+      const int pair = tid >> (2 * lb);
+      const int rem = tid & (b * b - 1);
+      const int ii = rem >> lb, c = rem & (b - 1);
+      const int r0 = 2 * b * pair;
+      row = r0 + b + ii;
+      col = r0 + c;
+      for (int k = c; k < b; ++k) t += S[row * PLD + r0 + k] * S[(r0 + k) * PLD + col];
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (rr[q] >= 0) S[rr[q] * PLD + cc[q]] = t[q];
+    if (row >= 0) S[row * PLD + col] = t;
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (rr[q] >= 0) {
-        const int row = rr[q];
-        const int rb = row & ~(2 * b - 1);  // r0
-        const int ii = row - rb - b;
-        double sum = 0.0;
-        for (int k = 0; k <= ii; ++k) sum += S[row * PLD + rb + b + k] * S[(rb + b + k) * PLD + cc[q]];
-        t[q] = -sum;
-      }
+    if (row >= 0) {
+      const int rb = row & ~(2 * b - 1);
+      const int ii = row - rb - b;
+      double sum = 0.0;
+      for (int k = 0; k <= ii; ++k) sum += S[row * PLD + rb + b + k] * S[(rb + b + k) * PLD + col];
+      t = -sum;
     }
     __syncthreads();
+    if (row >= 0) S[row * PLD + col] = t;
+    __syncthreads();
+  }
+  // ---- block sizes 16, 32, 64: MFMA.  b/4 output tiles of 16x16 per phase, one per wave.
+  const int lane = tid & 63, wv = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nlev_mfma = (dbg_skip & 2) ? 0 : 3;
+  for (int lv = 0; lv < nlev_mfma; ++lv) {
+    const int b = 16 << lv;
+    const int tpp = (b / 16) * (b / 16);  // tiles per pair
+    const int ntile = (64 / b) * tpp;     // 4, 8, 16
+    const bool act = wv < ntile;
+    int r0 = 0, trow = 0, tcol = 0;
+    if (act) {
+      const int pair = wv / tpp, tt = wv % tpp;
+      r0 = 2 * b * pair;
+      trow = (tt / (b / 16)) * 16;
+      tcol = (tt % (b / 16)) * 16;
+    }
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (act) {
+      // T = L21 * X11 : A = L21[trow + fr][k + fg], B = X11[k + fg][tcol + fr]  (zeros above the diagonal)
+      const double* Ap = S + (r0 + b + trow + fr) * PLD + r0 + fg;
+      const double* Bp = S + (r0 + fg) * PLD + r0 + tcol + fr;
+      for (int k = 0; k < b; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[k], Bp[k * PLD], acc, 0, 0, 0);
+    }
+    __syncthreads();
+    if (act) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (rr[q] >= 0) S[rr[q] * PLD + cc[q]] = t[q];
+      for (int r = 0; r < 4; ++r) S[(r0 + b + trow + fg + 4 * r) * PLD + r0 + tcol + fr] = acc[r];
+    }
+    __syncthreads();
+    acc = (d4){0.0, 0.0, 0.0, 0.0};
+    if (act) {
+      // X21 = -X22 * T : A = X22[trow + fr][k + fg], B = T[k + fg][tcol + fr]
+      const double* Ap = S + (r0 + b + trow + fr) * PLD + r0 + b + fg;
+      const double* Bp = S + (r0 + b + fg) * PLD + r0 + tcol + fr;
+      for (int k = 0; k < b; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[k], Bp[k * PLD], acc, 0, 0, 0);
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[(r0 + b + trow + fg + 4 * r) * PLD + r0 + tcol + fr] = -acc[r];
+    }
     __syncthreads();
   }
   for (int e = tid; e < 128 * 128; e += 1024) {
@@ -132,8 +216,8 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
 }
 
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0,
-                           int /*n_valid*/, hipStream_t s) {
-  hipLaunchKernelGGL(potf2_trtri_128_kernel, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0);
+                           int dbg_skip, hipStream_t s) {
+  hipLaunchKernelGGL(potf2_trtri_128_kernel, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
   GPK_HIP(hipGetLastError());
   return 0;
 }

@@ -105,8 +105,12 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
 int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile);
 /* device-resident timing of the MFMA GEMM: C (m x n) -= A (m x k) B (n x k)^T, `reps` launches; ms per launch. */
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out);
+/* leaf kernel timing; dbg_skip bit0 = skip elimination, bit1 = skip inverse (timing only). */
+int gpk_bench_leaf(int dbg_skip, int reps, double* us_out);
 /* pure v_mfma_f64_16x16x4_f64 issue loop on every CU: measured fp64 MFMA peak (TFLOP/s) of this device. */
 int gpk_bench_mfma_peak(int iters, double* tflops_out);
+int gpk_bench_mfma_mix(int mode, int waves_per_simd, int iters, double* tflops_out);
+int gpk_bench_mfma_peak2(int nacc, int waves_per_simd, int iters, double* tflops_out);
 /* factor one 128x128 SPD tile: L_out (128x128 lower) and Dinv_out = inv(L). Returns info. */
 int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out);
 
