@@ -134,59 +134,143 @@ int launch_gemvT_sub(const double* A, long lda, int m, int k, const double* x, d
 
 // In-place solve with the w x w diagonal block of a panel (ld = w), using the inverted 128-tiles.
 //   transpose = 0:  b <- Lpp^-1 b      transpose = 1:  b <- Lpp^-T b
-__global__ __launch_bounds__(256) void diag_solve_kernel(const double* __restrict__ Lp, int w,
-                                                         const double* __restrict__ Dinv, double* __restrict__ b,
-                                                         int transpose) {
-  extern __shared__ double sh[];  // x[w] + t[128]
-  double* x = sh;
-  double* t = sh + w;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ns = w / 128;
-  for (int i = tid; i < w; i += 256) x[i] = b[i];
-  __syncthreads();
-  if (!transpose) {
-    for (int s = 0; s < ns; ++s) {
-      // t = b_s - L[s rows][0 : 128 s] x[0 : 128 s]    (wave per row)
-      for (int r = wv; r < 128; r += 4) {
-        const double* a = Lp + (long)(s * 128 + r) * w;
-        double acc = 0.0;
-        for (int k = lane; k < s * 128; k += 64) acc += a[k] * x[k];
-        acc = wave_sum(acc);
-        if (lane == 0) t[r] = x[s * 128 + r] - acc;
-      }
-      __syncthreads();
-      // x_s = Dinv_s t
-      for (int r = wv; r < 128; r += 4) {
-        const double* a = Dinv + (long)s * 128 * 128 + r * 128;
-        double acc = a[lane] * t[lane] + a[lane + 64] * t[lane + 64];
-        acc = wave_sum(acc);
-        if (lane == 0) x[s * 128 + r] = acc;
-      }
-      __syncthreads();
-    }
-  } else {
-    for (int s = ns - 1; s >= 0; --s) {
-      // t[c] = b_s[c] - sum_{r >= (s+1)*128} L[r][s*128 + c] x[r]     (thread per column, coalesced rows)
-      if (tid < 128) {
-        double acc = 0.0;
-        for (int r = (s + 1) * 128; r < w; ++r) acc += Lp[(long)r * w + s * 128 + tid] * x[r];
-        t[tid] = x[s * 128 + tid] - acc;
-      }
-      __syncthreads();
-      // x_s[c] = sum_r Dinv_s[r][c] t[r]
-      if (tid < 128) {
-        const double* a = Dinv + (long)s * 128 * 128;
-        double acc = 0.0;
-        for (int r = tid; r < 128; ++r) acc += a[r * 128 + tid] * t[r];
-        x[s * 128 + tid] = acc;
-      }
-      __syncthreads();
+// One workgroup of 1024 threads; thread (r = tid>>3, part = tid&7) owns 16 contiguous columns of row r
+// of a 128x128 tile, so a tile is one fully coalesced 128 KiB load batch (16 doubles per thread), and
+// the next tile of the chain is prefetched while the current one is reduced.  All reductions are fixed
+// trees (shuffles + LDS), no float atomics: results are bit-reproducible.
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+__device__ inline void tile_load(const double* __restrict__ T, long ld, int r, int part, d2v (&v)[8]) {
+  const double* p = T + (long)r * ld + part * 16;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const d2v*>(p + 2 * q);
+}
+// y[r] = sum_c T[r][c] x[c]  -> result valid in lanes with part == 0
+__device__ inline double tile_row_dot(const d2v (&v)[8], const double* x, int part) {
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc += v[q].x * x[part * 16 + 2 * q] + v[q].y * x[part * 16 + 2 * q + 1];
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  return acc;
+}
+// out[c] = sum_r T[r][c] x[r] for the 16 columns of this thread, reduced over the 8 rows of the wave,
+// written to wp[wave][128]; the caller sums the 16 wave partials.
+__device__ inline void tile_col_dot(const d2v (&v)[8], double xr, int part, int lane, double* wp_wave) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    double a0 = v[q].x * xr, a1 = v[q].y * xr;
+    a0 += __shfl_xor(a0, 8, 64);  a1 += __shfl_xor(a1, 8, 64);
+    a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64);
+    a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
+    if (lane < 8) {
+      wp_wave[part * 16 + 2 * q] = a0;
+      wp_wave[part * 16 + 2 * q + 1] = a1;
     }
   }
-  for (int i = tid; i < w; i += 256) b[i] = x[i];
+}
+
+__global__ __launch_bounds__(1024) void diag_solve_kernel(const double* __restrict__ Lp, int w,
+                                                          const double* __restrict__ Dinv, double* __restrict__ b,
+                                                          int transpose) {
+  extern __shared__ double sh[];  // x[w] | t[128] | wp[16][128]
+  double* x = sh;
+  double* t = sh + w;
+  double* wp = t + 128;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = tid >> 3, part = tid & 7;
+  const int ns = w / 128;
+  for (int i = tid; i < w; i += 1024) x[i] = b[i];
+  d2v cur[8], nxt[8];
+  if (!transpose) {
+    // chain of tiles: for s = 0..ns-1: [L(s,0) .. L(s,s-1)] then D(s)
+    tile_load(Dinv, 128, r, part, cur);  // D(0)
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+      double racc = 0.0;  // sum_t L(s,t) x_t for row r (lanes with part == 0)
+      for (int tt = 0; tt <= s; ++tt) {
+        // prefetch the tile after (s,tt)
+        const bool last_of_row = (tt == s);
+        const bool have_next = !(last_of_row && s == ns - 1);
+        if (have_next) {
+          if (last_of_row) {  // next: L(s+1,0)
+            tile_load(Lp + (long)(s + 1) * 128 * w, w, r, part, nxt);
+          } else if (tt + 1 == s) {  // next: D(s)
+            tile_load(Dinv + (long)s * 128 * 128, 128, r, part, nxt);
+          } else {  // next: L(s, tt+1)
+            tile_load(Lp + (long)s * 128 * w + (tt + 1) * 128, w, r, part, nxt);
+          }
+        }
+        if (!last_of_row) {
+          racc += tile_row_dot(cur, x + tt * 128, part);
+        } else {
+          // t = b_s - racc, then x_s = D(s) t
+          if (part == 0) t[r] = x[s * 128 + r] - racc;
+          __syncthreads();
+          const double y = tile_row_dot(cur, t, part);
+          __syncthreads();
+          if (part == 0) x[s * 128 + r] = y;
+          __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+      }
+    }
+  } else {
+    // x_s = D(s)^T (b_s - sum_{u > s} L(u,s)^T x_u),  s = ns-1 .. 0
+    tile_load(Dinv + (long)(ns - 1) * 128 * 128, 128, r, part, cur);  // D(ns-1)
+    __syncthreads();
+    for (int s = ns - 1; s >= 0; --s) {
+      // accumulate sum_u L(u,s)^T x_u into t-space via wave partials
+      double cacc = 0.0;  // per column c = tid (tid < 128)
+      for (int u = ns - 1; u >= s; --u) {
+        const bool is_diag = (u == s);
+        const bool have_next = !(is_diag && s == 0);
+        if (have_next) {
+          if (is_diag) {  // next: L(ns-1, s-1) or D(s-1) when s-1 == ns-1 (impossible) -> first tile of row s-1 chain
+            if (ns - 1 > s - 1) tile_load(Lp + (long)(ns - 1) * 128 * w + (s - 1) * 128, w, r, part, nxt);
+            else tile_load(Dinv + (long)(s - 1) * 128 * 128, 128, r, part, nxt);
+          } else if (u - 1 == s) {  // next: D(s)
+            tile_load(Dinv + (long)s * 128 * 128, 128, r, part, nxt);
+          } else {  // next: L(u-1, s)
+            tile_load(Lp + (long)(u - 1) * 128 * w + s * 128, w, r, part, nxt);
+          }
+        }
+        if (!is_diag) {
+          tile_col_dot(cur, x[u * 128 + r], part, lane, wp + wv * 128);
+          __syncthreads();
+          if (tid < 128) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a += wp[k * 128 + tid];
+            cacc += a;
+          }
+          __syncthreads();
+        } else {
+          if (tid < 128) t[tid] = x[s * 128 + tid] - cacc;
+          __syncthreads();
+          tile_col_dot(cur, t[r], part, lane, wp + wv * 128);
+          __syncthreads();
+          if (tid < 128) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a += wp[k * 128 + tid];
+            x[s * 128 + tid] = a;
+          }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < w; i += 1024) b[i] = x[i];
 }
 int launch_diag_solve(const double* Lp, int w, const double* Dinv, double* b, int transpose, hipStream_t s) {
-  hipLaunchKernelGGL(diag_solve_kernel, dim3(1), dim3(256), (w + 128) * sizeof(double), s, Lp, w, Dinv, b, transpose);
+  hipLaunchKernelGGL(diag_solve_kernel, dim3(1), dim3(1024), (size_t)(w + 128 + 16 * 128) * sizeof(double), s, Lp, w, Dinv,
+                     b, transpose);
   GPK_HIP(hipGetLastError());
   return 0;
 }
