@@ -55,6 +55,7 @@ def _bind(l):
         "gpk_model_get_L": (i, [vp, dp]),
         "gpk_free": (i, [vp]),
         "gpk_last_timing": (i, [cp, dp, dp]),
+        "gpk_last_timing_work": (i, [cp, dp]),
         "gpk_bench_posterior": (i, [dp, dp, i, i, dp, dp, i, i, i, dp, dp, dp, dp]),
         "gpk_test_gemm_nt": (i, [dp, dp, dp, i, i, i, i, i, i]),
         "gpk_test_potf2_128": (i, [dp, dp, dp]),

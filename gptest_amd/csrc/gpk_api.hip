@@ -123,6 +123,12 @@ int gpk_set_option(const char* key, double value) {
   } else if (k == "gemm_variant") {
     extern int g_gemm_variant;
     g_gemm_variant = (int)value;
+  } else if (k == "xcd_sq") {
+    G.xcd_sq = (int)value;
+  } else if (k == "use_persistent") {
+    G.use_persistent = (int)value;
+  } else if (k == "persist_min_tiles") {
+    G.persist_min_tiles = (int)value;
   } else if (k == "use_pp") {
     G.use_pp = (int)value;
   } else if (k == "pp_min_tiles") {
@@ -416,6 +422,14 @@ int gpk_last_timing(const char* stage, double* ms_out, double* count_out) {
   return 0;
 }
 
+int gpk_last_timing_work(const char* stage, double* work_out) {
+  GPK_TRY(rt_require());
+  GPK_TRY(timers_resolve());
+  auto it = G.timers.find(stage ? stage : "");
+  if (work_out) *work_out = (it == G.timers.end()) ? 0.0 : it->second.work;
+  return 0;
+}
+
 int gpk_bench_posterior(const double* X, const double* y, int N, int d, const double* log_hyp, const double* Z, int M,
                         int warmup, int reps, double* ms_total_out, double* nlml_out, double* mean_out,
                         double* var_out) {
@@ -504,7 +518,7 @@ int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, 
     GemmNT g{};
     g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
     g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
-    rc = (tile == 1) ? launch_gemm_nt_pp(g, G.ncu, s) : launch_gemm_nt(g, tile == 128, s);
+    rc = (tile == 1) ? launch_gemm_nt_pp(g, G.ncu, s) : (tile == 9) ? launch_gemm_nt8p(g, s) : launch_gemm_nt(g, tile == 128, s);
     if (rc) break;
     if (hipMemcpyAsync(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
     if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "test_gemm: %s", hipGetErrorString(hipGetLastError())); break; }
@@ -733,7 +747,7 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
   const int saved_variant = g_gemm_variant;
   if (tile == 4) g_gemm_variant = 4;
   if (tile == 8) g_gemm_variant = 8;
-  auto go = [&]() { return (tile == 1) ? launch_gemm_nt_pp(g, G.ncu, s) : launch_gemm_nt(g, tile != 64, s); };
+  auto go = [&]() { return (tile == 1) ? launch_gemm_nt_pp(g, G.ncu, s) : (tile == 9) ? launch_gemm_nt8p(g, s) : launch_gemm_nt(g, tile != 64, s); };
   int rc = go();
   hipEvent_t e0, e1;
   GPK_HIP(hipEventCreate(&e0));

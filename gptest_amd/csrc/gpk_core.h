@@ -10,6 +10,8 @@ struct StageTimer {
   std::vector<Rec> recs;
   double ms = 0.0;
   double count = 0.0;
+  double work = 0.0;   // algorithmic flops (or bytes) of the recorded launches
+  double work_pending = 0.0;
 };
 
 struct Runtime {
@@ -26,6 +28,9 @@ struct Runtime {
   int nb = 256;
   int lookahead = 1;
   int timing = 0;
+  int xcd_sq = 1;              // XCD-aware 8x8-tile square order in the big GEMMs
+  int use_persistent = 0;      // persistent XCD-aware 8-wave kernel for the rank-NB updates
+  int persist_min_tiles = 1024; // below this many tiles the one-tile-per-workgroup kernel is used
   int use_pp = 0;        // experimental persistent pipelined GEMM (k_gemm_pp.hip); slower than the 8-wave kernel, off
   int pp_min_tiles = 384; // below this many 128x128 tiles the plain kernel (2 workgroups/CU) is used
   int ncu = 256;         // CUs available to the GEMM streams
@@ -44,7 +49,7 @@ int dev_alloc(void** p, size_t bytes);
 void dev_free(void* p, size_t bytes);
 template <class T> int dev_alloc_t(T** p, size_t n) { return dev_alloc((void**)p, n * sizeof(T)); }
 
-void timer_begin(const char* stage, hipStream_t s);
+void timer_begin(const char* stage, hipStream_t s, double work = 0.0);
 void timer_end(const char* stage, hipStream_t s);
 void timers_reset();
 int timers_resolve();

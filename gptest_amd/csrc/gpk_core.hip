@@ -22,6 +22,16 @@ int rt_require() {
 }
 
 int launch_gemm_auto(const GemmNT& g, hipStream_t s) {
+  if (G.use_persistent && g.sub && g.cyc_P == 0 && g.m % 128 == 0 && g.n % 128 == 0 && (!g.lower || g.m == g.n)) {
+    const long ntm = g.m / 128, ntn = g.n / 128;
+    const long nt = g.lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
+    if (nt >= G.persist_min_tiles) return launch_gemm_nt8p(g, s);
+  }
+  if (G.xcd_sq && g.cyc_P == 0 && g.m % 128 == 0 && g.n % 128 == 0 && (long)(g.m / 128) * (g.n / 128) >= 8192) {
+    GemmNT h = g;
+    h.xcd_sq = 1;
+    return launch_gemm_nt(h, true, s);
+  }
   if (G.use_pp && g.sub && g.cyc_P == 0 && (g.k == 256 || g.k == 512) && g.m % 128 == 0 && g.n % 128 == 0) {
     const long ntm = g.m / 128, ntn = g.n / 128;
     const long nt = g.lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
@@ -72,9 +82,10 @@ static hipEvent_t ev_get() {
   (void)hipEventCreate(&e);
   return e;
 }
-void timer_begin(const char* stage, hipStream_t s) {
+void timer_begin(const char* stage, hipStream_t s, double work) {
   if (!G.timing) return;
   StageTimer& t = G.timers[stage];
+  t.work_pending += work;
   StageTimer::Rec r;
   r.a = ev_get();
   r.b = nullptr;
@@ -98,6 +109,8 @@ void timers_reset() {
     kv.second.recs.clear();
     kv.second.ms = 0;
     kv.second.count = 0;
+    kv.second.work = 0;
+    kv.second.work_pending = 0;
   }
 }
 int timers_resolve() {
@@ -116,6 +129,8 @@ int timers_resolve() {
       if (r.b) G.ev_free.push_back(r.b);
     }
     t.recs.clear();
+    t.work += t.work_pending;
+    t.work_pending = 0;
   }
   return 0;
 }
@@ -292,7 +307,7 @@ int potrf_device(gpk_model* m) {
       GPK_TRY(factor_panel(m, p, sm));
       timer_end("panel", sm);
       const int r0 = m->pc0[p] + m->pw[p];
-      timer_begin("trailing", sm);
+      timer_begin("trailing", sm, (double)(m->Npad - r0) * (m->Npad - r0) * m->pw[p]);
       GPK_TRY(panel_update(m, p, r0, r0, m->Npad - r0, 1, sm));
       timer_end("trailing", sm);
     }
@@ -322,7 +337,7 @@ int potrf_device(gpk_model* m) {
     GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
     const int r1 = r0 + wn;
     if (m->Npad - r1 > 0) {
-      timer_begin("trailing", sm);
+      timer_begin("trailing", sm, (double)(m->Npad - r1) * (m->Npad - r1) * m->pw[p]);
       GPK_TRY(panel_update(m, p, r1, r1, m->Npad - r1, 1, sm));
       timer_end("trailing", sm);
     }
@@ -359,7 +374,7 @@ int trsv_backward(gpk_model* m, double* v) {
 int fit_device(gpk_model* m) {
   hipStream_t s = G.s_main;
   const int np_ = m->Npad;
-  timer_begin("kbuild", s);
+  timer_begin("kbuild", s, (m->keep_k ? 8.0 : 4.0) * np_ * np_ + 8.0 * m->N * m->d);
   GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, np_, m->keep_k ? 0 : 1, s));
   timer_end("kbuild", s);
   if (m->keep_k)

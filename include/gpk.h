@@ -94,6 +94,8 @@ int gpk_free(gpk_model* h);
 /* HIP-event timings (ms) of the stages of the last gpk_fit / gpk_predict on this
  * process; names: "kbuild","potrf","trailing","panel","solve_y","predict".      */
 int gpk_last_timing(const char* stage, double* ms_out, double* count_out);
+/* algorithmic work (flops for "trailing", bytes for "kbuild") of the launches summed by gpk_last_timing. */
+int gpk_last_timing_work(const char* stage, double* work_out);
 /* Stage inputs once (X,y,Z resident in HBM) and run fit+predict `reps` times
  * without any host<->device traffic inside the timed region; returns total ms.  */
 int gpk_bench_posterior(const double* X, const double* y, int N, int d, const double* log_hyp,
