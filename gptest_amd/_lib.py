@@ -59,6 +59,7 @@ def _bind(l):
         "gpk_bench_posterior": (i, [dp, dp, i, i, dp, dp, i, i, i, dp, dp, dp, dp]),
         "gpk_test_gemm_nt": (i, [dp, dp, dp, i, i, i, i, i, i]),
         "gpk_test_potf2_128": (i, [dp, dp, dp]),
+        "gpk_test_dist_potrf": (i, [dp, i, i, dp]),
         "gpk_bench_gemm_nt": (i, [i, i, i, i, i, i, dp]),
         "gpk_bench_mfma_peak": (i, [i, dp]),
         "gpk_bench_mfma_peak2": (i, [i, i, i, dp]),

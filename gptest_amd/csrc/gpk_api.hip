@@ -219,6 +219,8 @@ static int model_unpack_L(gpk_model* m, double* L_out_host) {
   double* dOut = nullptr;
   GPK_TRY(dev_alloc_t(&dOut, (size_t)N * N));
   int rc = 0;
+  // blocks above the panels are never touched by the unpack kernel: the strict upper triangle must be zero
+  if (hipMemsetAsync(dOut, 0, (size_t)N * N * 8, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
   for (int p = 0; p < m->nP && !rc; ++p)
     rc = launch_unpack_L(m->Lpanel(p), m->pw[p], m->Npad - m->pc0[p], m->pc0[p], dOut, N, s);
   if (!rc && hipMemcpyAsync(L_out_host, dOut, (size_t)N * N * 8, hipMemcpyDeviceToHost, s) != hipSuccess) rc = gpk_set_err(-2, "D2H failed");
@@ -501,7 +503,77 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
 }  // extern "C"
 
 // ---------------------------------------------------------------- kernel-level test hooks
+__global__ void pad_diag_local_kernel(double* K, long ldk, int N, int Npad, int NB, int P, int r) {
+  // ones on the padded diagonal entries (i >= N) that fall into this rank's block columns
+  for (int i = N + blockIdx.x * blockDim.x + threadIdx.x; i < Npad; i += gridDim.x * blockDim.x) {
+    const int g = i / NB;
+    if (g % P == r) K[(long)i * ldk + (long)(g / P) * NB + (i % NB)] = 1.0;
+  }
+}
+
 extern "C" {
+
+// Single-GPU emulation of the P-rank block-cyclic factorisation: P rank models live in this process,
+// the RCCL broadcast is replaced by device-to-device copies, everything else (ownership, local column
+// maps, the cyclic GEMM column map) is the production code.  L of rank `P-1` is returned.
+int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
+  GPK_TRY(rt_require());
+  if (!A || !L_out || N < 1 || P < 1 || P > 16) return gpk_set_err(-1, "gpk_test_dist_potrf: bad arguments");
+  hipStream_t s = G.s_main;
+  std::vector<gpk_model*> ms(P, nullptr);
+  int rc = 0;
+  for (int r = 0; r < P && !rc; ++r) rc = model_create(&ms[r], N, 1, false, P, r);
+  if (!rc) {
+    const int NB = ms[0]->NB, nP = ms[0]->nP, np_ = ms[0]->Npad;
+    for (int r = 0; r < P && !rc; ++r) {
+      gpk_model* m = ms[r];
+      if (hipMemsetAsync(m->dK, 0, (size_t)np_ * m->ldk * 8, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
+      if (hipMemsetAsync(m->dinfo, 0, 16, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
+      for (int lg = 0; lg < m->nloc && !rc; ++lg) {
+        const int g = (P > 1) ? lg * P + r : lg;
+        const int cg0 = g * NB;
+        int nc = N - cg0;
+        if (nc > NB) nc = NB;
+        if (nc <= 0) continue;
+        if (hipMemcpy2DAsync(m->dK + (size_t)lg * NB, (size_t)m->ldk * 8, A + cg0, (size_t)N * 8, (size_t)nc * 8, N,
+                             hipMemcpyHostToDevice, s) != hipSuccess)
+          rc = gpk_set_err(-2, "H2D failed");
+      }
+      if (!rc && np_ > N) hipLaunchKernelGGL(pad_diag_local_kernel, dim3(8), dim3(256), 0, s, m->dK, m->ldk, N, np_, NB, P, r);
+    }
+    for (int p = 0; p < nP && !rc; ++p) {
+      gpk_model* own = ms[p % P];
+      rc = factor_panel(own, p, s);
+      const int c0 = own->pc0[p], w = own->pw[p];
+      for (int r = 0; r < P && !rc; ++r) {
+        if (r == p % P) continue;
+        if (hipMemcpyAsync(ms[r]->Lpanel(p), own->Lpanel(p), (size_t)(np_ - c0) * w * 8, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(ms[r]->dDinv + (size_t)(c0 / 128) * 16384, own->dDinv + (size_t)(c0 / 128) * 16384,
+                           (size_t)(w / 128) * 16384 * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+          rc = gpk_set_err(-2, "D2D failed");
+      }
+      for (int r = 0; r < P && !rc; ++r) {
+        gpk_model* m = ms[r];
+        const int lg0 = (p >= r) ? (p - r) / P + 1 : 0;
+        rc = (P > 1) ? dist_update(m, p, lg0, 1 << 30, s)
+                     : panel_update(m, p, c0 + w, c0 + w, np_ - c0 - w, 1, s);
+      }
+    }
+    int worst = 0;
+    for (int r = 0; r < P && !rc; ++r) {
+      int hinfo = 0;
+      if (hipMemcpyAsync(&hinfo, ms[r]->dinfo, 4, hipMemcpyDeviceToHost, s) != hipSuccess) rc = gpk_set_err(-2, "D2H failed");
+      if (hipStreamSynchronize(s) != hipSuccess) rc = gpk_set_err(-2, "dist potrf: %s", hipGetErrorString(hipGetLastError()));
+      if (hinfo > worst) worst = hinfo;
+    }
+    if (!rc && worst > 0) rc = worst > N ? N : worst;
+    if (!rc) rc = model_unpack_L(ms[P - 1], L_out);
+  }
+  for (int r = 0; r < P; ++r)
+    if (ms[r]) model_destroy(ms[r]);
+  return rc;
+}
+
 
 int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile) {
   GPK_TRY(rt_require());

@@ -56,6 +56,11 @@ int timers_resolve();
 
 struct gpk_model {
   int N = 0, d = 0, Npad = 0, nT = 0, NB = 0, nP = 0;
+  // 1-D block-cyclic column ownership of K: panel g belongs to rank g % P; this rank
+  // stores only its nloc block columns, side by side, in dK (Npad x ldk).  P = 1: ldk = Npad.
+  int P = 1, r = 0, nloc = 0;
+  long ldk = 0;
+  bool virtual_rank = false;  // single-process emulation of rank r of P (tests): no RCCL calls
   std::vector<int> pc0, pw;
   std::vector<size_t> poff;
   size_t L_elems = 0;
@@ -72,11 +77,16 @@ struct gpk_model {
   double* Lpanel(int p) const { return dL + poff[p]; }
 };
 
-int model_create(gpk_model** out, int N, int d, bool keep_k);
+int model_create(gpk_model** out, int N, int d, bool keep_k, int P = -1, int r = -1);
 void model_destroy(gpk_model* m);
 int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m);
 int fit_device(gpk_model* m);                                   // K build + potrf + w + scalars (inputs resident)
 int potrf_device(gpk_model* m);                                 // dK -> dL, dDinv
+int build_K(gpk_model* m);                                      // dX -> dK (local block columns)
+int factor_panel(gpk_model* m, int p, hipStream_t s);          // owner only
+int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hipStream_t s);
+int dist_update(gpk_model* m, int p, int first_block, int nblocks_max, hipStream_t s);  // cyclic trailing update
+int comm_bcast(double* buf, size_t count, int root, hipStream_t s);
 int trsv_forward(gpk_model* m, double* v);                      // v <- L^-1 v  (Npad vector)
 int trsv_backward(gpk_model* m, double* v);                     // v <- L^-T v
 int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, double* dV, double* dmean, double* dvar);

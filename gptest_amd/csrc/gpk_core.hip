@@ -3,6 +3,7 @@
 #include <cmath>
 
 Runtime G;
+extern "C" int gpk_comm_allreduce_max(double* inout, int n);
 static thread_local std::string g_err = "";
 
 int gpk_set_err(int code, const char* fmt, ...) {
@@ -136,7 +137,7 @@ int timers_resolve() {
 }
 
 // ------------------------------------------------------------------ model
-int model_create(gpk_model** out, int N, int d, bool keep_k) {
+int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r) {
   GPK_TRY(rt_require());
   if (N < 1) return gpk_set_err(-1, "N=%d must be >= 1", N);
   if (d < 1 || d > 32) return gpk_set_err(-1, "input dimension d=%d outside 1..32", d);
@@ -147,7 +148,11 @@ int model_create(gpk_model** out, int N, int d, bool keep_k) {
   if (nb < 128) nb = 128;
   nb = nb / 128 * 128;
   m->NB = nb;
-  m->Npad = (G.nranks > 1) ? round_up(N, nb) : round_up(N, GPK_T);
+  if (P < 1) { P = G.nranks; r = G.rank; } else { m->virtual_rank = true; }
+  m->P = P;
+  m->r = r;
+  if (P > 1 && keep_k) { delete m; return gpk_set_err(-1, "keep-K models are single-GPU only"); }
+  m->Npad = (P > 1) ? round_up(N, nb) : round_up(N, GPK_T);
   m->nT = m->Npad / GPK_T;
   size_t off = 0;
   for (int c0 = 0; c0 < m->Npad; c0 += nb) {
@@ -159,13 +164,17 @@ int model_create(gpk_model** out, int N, int d, bool keep_k) {
   }
   m->nP = (int)m->pc0.size();
   m->L_elems = off;
+  m->nloc = 0;
+  for (int g = 0; g < m->nP; ++g)
+    if (g % P == r) m->nloc++;
+  m->ldk = (P > 1) ? (long)std::max(m->nloc, 1) * nb : (long)m->Npad;
   m->keep_k = keep_k;
   const size_t np = m->Npad;
   int rc = 0;
   rc |= dev_alloc_t(&m->dX, (size_t)N * d);
   rc |= dev_alloc_t(&m->dy, np);
   rc |= dev_alloc_t(&m->dw, np);
-  rc |= dev_alloc_t(&m->dK, np * np);
+  rc |= dev_alloc_t(&m->dK, np * (size_t)m->ldk);
   if (keep_k) rc |= dev_alloc_t(&m->dKcopy, np * np);
   rc |= dev_alloc_t(&m->dL, m->L_elems);
   rc |= dev_alloc_t(&m->dDinv, (size_t)m->nT * 128 * 128);
@@ -186,7 +195,7 @@ void model_destroy(gpk_model* m) {
   dev_free(m->dX, (size_t)m->N * m->d * 8);
   dev_free(m->dy, np * 8);
   dev_free(m->dw, np * 8);
-  dev_free(m->dK, np * np * 8);
+  dev_free(m->dK, np * (size_t)m->ldk * 8);
   if (m->dKcopy) dev_free(m->dKcopy, np * np * 8);
   dev_free(m->dL, m->L_elems * 8);
   dev_free(m->dDinv, (size_t)m->nT * 128 * 128 * 8);
@@ -241,29 +250,31 @@ static int launch_leaf(const double* A, long lda, double* L, long ldl, double* D
   return 0;
 }
 
-static int factor_panel(gpk_model* m, int p, hipStream_t s) {
+int factor_panel(gpk_model* m, int p, hipStream_t s) {
   const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
+  const long ldk = m->ldk;
+  const long kc0 = (m->P > 1) ? (long)(p / m->P) * m->NB : (long)c0;  // local column of global column c0
   double* Lp = m->Lpanel(p);
   const int h = np_ - c0;
   for (int sb = 0; sb < w / 128; ++sb) {
     const int cs = c0 + sb * 128;   // global column of this sub-panel
     const int ro = cs - c0;         // row offset inside the panel
-    double* Acol = m->dK + (long)cs * np_ + cs;  // A[cs, cs]
+    double* Acol = m->dK + (long)cs * ldk + kc0 + sb * 128;  // A[cs, cs]
     if (sb > 0) {
       // A[cs:, cs:cs+128] -= Lp[ro:, 0:ro] * Lp[ro:ro+128, 0:ro]^T
       GemmNT g{};
       g.A = Lp + (long)ro * w; g.lda = w;
       g.B = Lp + (long)ro * w; g.ldb = w;
-      g.C = Acol; g.ldc = np_;
+      g.C = Acol; g.ldc = ldk;
       g.m = h - ro; g.n = 128; g.k = ro; g.sub = 1;
       GPK_TRY(launch_gemm_nt(g, false, s));
     }
     double* Dt = m->dDinv + (long)(cs / 128) * 128 * 128;
-    GPK_TRY(launch_leaf(Acol, np_, Lp + (long)ro * w + sb * 128, w, Dt, m->dinfo, cs, s));
+    GPK_TRY(launch_leaf(Acol, ldk, Lp + (long)ro * w + sb * 128, w, Dt, m->dinfo, cs, s));
     if (h - ro - 128 > 0) {
       // L[cs+128:, sub-panel] = A[cs+128:, cs:cs+128] * Dinv^T
       GemmNT g{};
-      g.A = Acol + (long)128 * np_; g.lda = np_;
+      g.A = Acol + (long)128 * ldk; g.lda = ldk;
       g.B = Dt; g.ldb = 128;
       g.C = Lp + (long)(ro + 128) * w + sb * 128; g.ldc = w;
       g.m = h - ro - 128; g.n = 128; g.k = 128; g.sub = 0;
@@ -275,7 +286,7 @@ static int factor_panel(gpk_model* m, int p, hipStream_t s) {
 
 // A[r0g:, c0g : c0g+ncols] -= Lp[(r0g-c0p):, :] * Lp[(c0g-c0p) : +ncols, :]^T   (rows r0g.., global indices)
 // lower = 1: square region on the diagonal (r0g == c0g, ncols == rows), only tiles on/below it.
-static int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hipStream_t s) {
+int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hipStream_t s) {
   const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
   const int rows = np_ - r0g;
   if (rows <= 0 || ncols <= 0) return 0;
@@ -288,6 +299,27 @@ static int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lo
   return launch_gemm_auto(g, s);
 }
 
+// Distributed trailing update of panel p on THIS rank's block columns: local blocks lg >= first_block
+// (at most nblocks_max of them), rows from the end of panel p's diagonal block.  The kernel maps local
+// tile columns to global columns (GemmNT.cyc_*) for the B-operand rows and the lower-triangle test.
+int dist_update(gpk_model* m, int p, int first_block, int nblocks_max, hipStream_t s) {
+  const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
+  const int r0 = c0 + w;
+  const int rows = np_ - r0;
+  int nb_ = m->nloc - first_block;
+  if (nb_ > nblocks_max) nb_ = nblocks_max;
+  if (rows <= 0 || nb_ <= 0) return 0;
+  double* Lp = m->Lpanel(p);
+  GemmNT g{};
+  g.A = Lp + (long)w * w; g.lda = w;
+  g.B = g.A; g.ldb = w;
+  g.C = m->dK + (long)r0 * m->ldk + (long)first_block * m->NB; g.ldc = m->ldk;
+  g.m = rows; g.n = nb_ * m->NB; g.k = w; g.sub = 1; g.lower = 1;
+  g.cyc_P = m->P; g.cyc_r = m->r; g.cyc_NB = m->NB; g.cyc_lg0 = first_block;
+  g.row_g0 = r0; g.brow_g0 = r0;
+  return launch_gemm_nt(g, true, s);
+}
+
 static hipEvent_t ev_new() {
   hipEvent_t e;
   (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -297,10 +329,13 @@ static hipEvent_t ev_new() {
 // Right-looking with one panel of look-ahead: while the big SYRK of panel p runs on s_main, the
 // high-priority s_panel stream updates block column p+1 and factors panel p+1, so the latency-bound
 // leaf/panel kernels leave the critical path.
+static int potrf_distributed(gpk_model* m);
+
 int potrf_device(gpk_model* m) {
   hipStream_t sm = G.s_main, sp = G.s_panel;
   GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
   const int nP = m->nP;
+  if (m->P > 1) return potrf_distributed(m);
   if (!G.lookahead || nP < 3) {
     for (int p = 0; p < nP; ++p) {
       timer_begin("panel", sm);
@@ -348,6 +383,90 @@ int potrf_device(gpk_model* m) {
   return 0;
 }
 
+// One process per GPU, panels owned block-cyclically.  Step p: the owner factors panel p from its local
+// block column, the factored panel (and its inverted diagonal tiles) is broadcast with RCCL over xGMI,
+// every rank updates the block columns it owns.  Look-ahead: the owner of panel p+1 updates THAT block
+// column first, factors it and starts its broadcast on the panel stream while all ranks run the rest
+// of update p on the main stream.
+static int bcast_panel(gpk_model* m, int p, hipStream_t s) {
+  if (m->virtual_rank) return 0;  // the emulation harness copies panels between its rank models
+  const int c0 = m->pc0[p], w = m->pw[p];
+  const size_t cnt = (size_t)(m->Npad - c0) * w;
+  GPK_TRY(comm_bcast(m->Lpanel(p), cnt, p % m->P, s));
+  GPK_TRY(comm_bcast(m->dDinv + (size_t)(c0 / 128) * 128 * 128, (size_t)(w / 128) * 128 * 128, p % m->P, s));
+  return 0;
+}
+static inline int first_local_block_after(const gpk_model* m, int p) {  // # local blocks with global index <= p
+  return (p >= m->r) ? (p - m->r) / m->P + 1 : 0;
+}
+
+static int potrf_distributed(gpk_model* m) {
+  hipStream_t sm = G.s_main, sp = G.s_panel;
+  const int nP = m->nP, P = m->P, r = m->r;
+  if (!G.lookahead || nP < 3 || m->virtual_rank) {
+    for (int p = 0; p < nP; ++p) {
+      if (p % P == r) GPK_TRY(factor_panel(m, p, sm));
+      GPK_TRY(bcast_panel(m, p, sm));
+      timer_begin("trailing", sm);
+      GPK_TRY(dist_update(m, p, first_local_block_after(m, p), 1 << 30, sm));
+      timer_end("trailing", sm);
+    }
+    return 0;
+  }
+  while ((int)G.ev_pool.size() < 2 * nP + 2) {
+    hipEvent_t e;
+    GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    G.ev_pool.push_back(e);
+  }
+  hipEvent_t* ev_panel = G.ev_pool.data();       // panel p available on this rank (recorded on s_panel)
+  hipEvent_t* ev_trail = G.ev_pool.data() + nP;  // rest-update of step p done (recorded on s_main)
+  hipEvent_t ev_start = G.ev_pool[2 * nP];
+  GPK_HIP(hipEventRecord(ev_start, sm));
+  GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
+  if (0 % P == r) GPK_TRY(factor_panel(m, 0, sp));
+  GPK_TRY(bcast_panel(m, 0, sp));
+  GPK_HIP(hipEventRecord(ev_panel[0], sp));
+  for (int p = 0; p < nP; ++p) {
+    const int lg0 = first_local_block_after(m, p);
+    const bool own_next = (p + 1 < nP) && ((p + 1) % P == r);
+    if (p + 1 < nP) {
+      if (own_next) {  // block column p+1 is my local block lg0 (the first one after p)
+        if (p > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[p - 1], 0));  // its earlier updates ran on s_main
+        GPK_TRY(dist_update(m, p, lg0, 1, sp));
+        GPK_TRY(factor_panel(m, p + 1, sp));
+      }
+      GPK_TRY(bcast_panel(m, p + 1, sp));  // every rank takes part; ordered after update p-1 on all ranks
+      GPK_HIP(hipEventRecord(ev_panel[p + 1], sp));
+    }
+    GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
+    timer_begin("trailing", sm);
+    GPK_TRY(dist_update(m, p, lg0 + (own_next ? 1 : 0), 1 << 30, sm));
+    timer_end("trailing", sm);
+    GPK_HIP(hipEventRecord(ev_trail[p], sm));
+  }
+  GPK_HIP(hipStreamWaitEvent(sm, ev_panel[nP - 1], 0));
+  return 0;
+}
+
+// K(X,X) into this rank's block columns (only tiles on/below the diagonal unless a full copy is kept)
+int build_K(gpk_model* m) {
+  hipStream_t s = G.s_main;
+  const int np_ = m->Npad;
+  if (m->P == 1)
+    return launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, np_, m->keep_k ? 0 : 1, s);
+  for (int lg = 0; lg < m->nloc; ++lg) {
+    const int g = lg * m->P + m->r;
+    const int cg0 = g * m->NB;
+    int nc = m->N - cg0;
+    if (nc > m->NB) nc = m->NB;
+    if (nc < 0) nc = 0;
+    // column points of this block (clamped pointer: nc == 0 blocks are pure padding)
+    const double* Cc = m->dX + (size_t)(nc > 0 ? cg0 : 0) * m->d;
+    GPK_TRY(launch_se_build(m->dX, m->N, np_, Cc, nc, m->NB, m->se, 1, 0, m->dK + (size_t)lg * m->NB, m->ldk, 1, s, cg0));
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------ triangular solves, single right-hand side
 int trsv_forward(gpk_model* m, double* v) {
   hipStream_t s = G.s_main;
@@ -375,7 +494,7 @@ int fit_device(gpk_model* m) {
   hipStream_t s = G.s_main;
   const int np_ = m->Npad;
   timer_begin("kbuild", s, (m->keep_k ? 8.0 : 4.0) * np_ * np_ + 8.0 * m->N * m->d);
-  GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, np_, m->keep_k ? 0 : 1, s));
+  GPK_TRY(build_K(m));
   timer_end("kbuild", s);
   if (m->keep_k)
     GPK_HIP(hipMemcpyAsync(m->dKcopy, m->dK, (size_t)np_ * np_ * 8, hipMemcpyDeviceToDevice, s));
@@ -395,6 +514,11 @@ int fit_device(gpk_model* m) {
   GPK_HIP(hipMemcpyAsync(hs, m->dscal, 16, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipStreamSynchronize(s));
+  if (m->P > 1 && !m->virtual_rank) {  // only the owner of the failing panel saw it
+    double hi = (double)hinfo;
+    GPK_TRY(gpk_comm_allreduce_max(&hi, 1));
+    hinfo = (int)hi;
+  }
   m->info = hinfo;
   if (hinfo > 0) return hinfo > m->N ? m->N : hinfo;
   m->logdet = hs[0];

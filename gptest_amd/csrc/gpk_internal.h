@@ -71,7 +71,7 @@ struct SEParams {
 // mode 0: sf2*exp(-0.5*r2) (+diag_add where global r == c if same_set); padded entries: identity if same_set else 0
 // mode 1: plain squared distance r2 (scaled by inv_ell, pass ones for raw)
 int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p,
-                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s);
+                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0 = 0);
 
 // ---------------------------------------------------------------- aux kernels
 int launch_sum_log_diag(const double* Dinv, int N, double* out, hipStream_t s);              // -sum log Dinv_ii, i < N

@@ -18,13 +18,14 @@ template <int D>  // D = 0: runtime dimension (column points re-read from LDS)
 __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict__ R, int nr,
                                                        const double* __restrict__ Cc, int nc, SEParams p,
                                                        int same_set, int mode, int lower_only,
-                                                       double* __restrict__ out, long ld) {
+                                                       double* __restrict__ out, long ld, int col_g0) {
   constexpr int DMAX = (D == 0) ? 32 : D;
   __shared__ double rs[128 * DMAX];
   __shared__ double cs[(D == 0) ? 128 * DMAX : 1];
   const int d = (D == 0) ? p.d : D;
   const int tc = blockIdx.x, tr = blockIdx.y;
-  if (lower_only && tc > tr) return;
+  // col_g0: global index of column 0 of this call (block-cyclic local column blocks); Cc/out are already offset
+  if (lower_only && col_g0 + tc * 128 > tr * 128 + 127) return;
   const int r0 = tr * 128, c0 = tc * 128;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
@@ -76,20 +77,20 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
       v0 = p.sf2 * exp(-0.5 * s0);
       v1 = p.sf2 * exp(-0.5 * s1);
       if (same_set) {
-        if (gi == ca) v0 += p.diag_add;
-        if (gi == cb) v1 += p.diag_add;
+        if (gi == col_g0 + ca) v0 += p.diag_add;
+        if (gi == col_g0 + cb) v1 += p.diag_add;
       }
     }
     const bool rok = gi < nr;
-    if (!(rok && ca < nc)) v0 = (same_set && gi == ca) ? 1.0 : 0.0;  // padding: identity / zero
-    if (!(rok && cb < nc)) v1 = (same_set && gi == cb) ? 1.0 : 0.0;
+    if (!(rok && ca < nc)) v0 = (same_set && gi == col_g0 + ca) ? 1.0 : 0.0;  // padding: identity / zero
+    if (!(rok && cb < nc)) v1 = (same_set && gi == col_g0 + cb) ? 1.0 : 0.0;
     d2 o = {v0, v1};
     *reinterpret_cast<d2*>(out + (long)gi * ld + ca) = o;
   }
 }
 
 int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p,
-                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s) {
+                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0) {
   if (nr_pad % 128 || nc_pad % 128 || (ld & 1) || ((uintptr_t)out & 15))
     return gpk_set_err(-1, "se_build: padded shape %dx%d ld %ld must be tile aligned", nr_pad, nc_pad, ld);
   if (p.d < 1 || p.d > 32) return gpk_set_err(-1, "se_build: input dimension d=%d outside 1..32", p.d);
@@ -97,7 +98,7 @@ int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int n
   const int lo = (int)lower_only;
 #define GPK_SE_CASE(DD)                                                                                            \
   case DD:                                                                                                         \
-    hipLaunchKernelGGL(se_build_kernel<DD>, grid, block, 0, s, R, nr, Cc, nc, p, same_set, mode, lo, out, ld); \
+    hipLaunchKernelGGL(se_build_kernel<DD>, grid, block, 0, s, R, nr, Cc, nc, p, same_set, mode, lo, out, ld, col_g0); \
     break;
   switch (p.d) {
     GPK_SE_CASE(1)
@@ -109,7 +110,7 @@ int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int n
     GPK_SE_CASE(7)
     GPK_SE_CASE(8)
     default:
-      hipLaunchKernelGGL(se_build_kernel<0>, grid, block, 0, s, R, nr, Cc, nc, p, same_set, mode, lo, out, ld);
+      hipLaunchKernelGGL(se_build_kernel<0>, grid, block, 0, s, R, nr, Cc, nc, p, same_set, mode, lo, out, ld, col_g0);
   }
 #undef GPK_SE_CASE
   GPK_HIP(hipGetLastError());

@@ -105,6 +105,8 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
 /* ---- kernel-level test hooks (tests/ only; host buffers, row-major) --------- */
 /* C (m x n) = [C -] A (m x k) * B (n x k)^T through the MFMA kernel; tile = 128 or 64. */
 int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile);
+/* single-GPU emulation of the P-rank block-cyclic Cholesky (RCCL broadcast replaced by D2D copies). */
+int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out);
 /* device-resident timing of the MFMA GEMM: C (m x n) -= A (m x k) B (n x k)^T, `reps` launches; ms per launch. */
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out);
 /* leaf kernel timing; dbg_skip bit0 = skip elimination, bit1 = skip inverse (timing only). */

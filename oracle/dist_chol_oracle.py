@@ -1,0 +1,43 @@
+"""NumPy restatement of the multi-GPU algorithm (TEST INFRASTRUCTURE ONLY): right-looking blocked
+Cholesky with 1-D block-cyclic column ownership and one broadcast of the factored panel per step
+(SURVEY.md 8e).  The reference has no distributed code; this exists so the N>1 schedule can be checked on
+CPU over gloo (tests/test_dist_gloo.py).  Each rank holds only its own block columns of A plus the
+panels it received, exactly like gptest_amd/csrc/gpk_core.hip: potrf_distributed."""
+import numpy as np
+
+
+def torch_bcast(arr, root):
+    import torch
+    import torch.distributed as tdist
+
+    t = torch.from_numpy(arr)
+    tdist.broadcast(t, src=root)
+    return t.numpy()
+
+
+def cholesky_block_cyclic(A, nb, rank, world, bcast):
+    N = A.shape[0]
+    nP = (N + nb - 1) // nb
+    mine = [g for g in range(nP) if g % world == rank]
+    local = {g: A[:, g * nb:min(N, (g + 1) * nb)].copy() for g in mine}  # my block columns (all rows)
+    L = np.zeros_like(A)
+    for p in range(nP):
+        c0, c1 = p * nb, min(N, (p + 1) * nb)
+        w = c1 - c0
+        panel = np.empty((N - c0, w))
+        if p % world == rank:
+            blk = local[p]
+            L11 = np.linalg.cholesky(blk[c0:c1, :])
+            panel[:w] = L11
+            if c1 < N:  # L21 = A21 * inv(L11)^T, the inverse applied as a product like the GPU path
+                panel[w:] = blk[c1:, :] @ np.linalg.inv(L11).T
+        panel = bcast(panel, p % world)
+        L[c0:, c0:c1] = panel
+        P21 = panel[w:]
+        for g in mine:
+            if g <= p:
+                continue
+            g0, g1 = g * nb, min(N, (g + 1) * nb)
+            # rows below panel p's diagonal block; B rows = the panel rows of MY global columns
+            local[g][c1:, :] -= P21 @ P21[g0 - c1:g1 - c1].T
+    return np.tril(L)

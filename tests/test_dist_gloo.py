@@ -1,0 +1,80 @@
+"""CPU, world_size 2 over gloo: the host side of the multi-GPU path (rank discovery, block-cyclic
+ownership, unique-id ferrying) and the distributed algorithm itself restated in NumPy with a real
+torch.distributed broadcast per panel (oracle/dist_chol_oracle.py)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from gptest_amd import dist
+
+
+def test_block_cyclic_ownership():
+    for world in (1, 2, 3, 8):
+        for nblocks in (1, 5, 16, 17):
+            seen = []
+            for r in range(world):
+                mine = dist.local_blocks(r, world, nblocks)
+                assert all(dist.block_cyclic_owner(b, world) == r for b in mine)
+                seen += mine
+            assert sorted(seen) == list(range(nblocks))
+
+
+def test_env_rank_parsing(monkeypatch):
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert dist.env_rank() == (3, 1, 4)
+    monkeypatch.setenv("RANK", "4")
+    with pytest.raises(ValueError):
+        dist.env_rank()
+
+
+WORKER = textwrap.dedent(
+    """
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    import torch.distributed as tdist
+    from gptest_amd import dist
+    from oracle import dist_chol_oracle as dco
+
+    rank, local, world = dist.env_rank()
+    tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    # (1) the unique-id bootstrap: rank 0's 128 bytes reach every rank unchanged
+    payload = bytes(range(128)) if rank == 0 else None
+    got = dist.torch_bootstrap(payload)
+    assert got == bytes(range(128)), got[:8]
+    # (2) block-cyclic right-looking Cholesky with one broadcast per panel, against LAPACK
+    rng = np.random.RandomState(5)
+    N, nb = 200, 32
+    Q = rng.randn(N, N)
+    A = Q @ Q.T + N * np.eye(N)
+    L = dco.cholesky_block_cyclic(A, nb, rank, world, dco.torch_bcast)
+    ref = np.linalg.cholesky(A)
+    assert np.allclose(L, ref, rtol=1e-11, atol=1e-11), np.abs(L - ref).max()
+    tdist.barrier()
+    tdist.destroy_process_group()
+    print("rank", rank, "ok")
+    """
+)
+
+
+def test_two_rank_gloo_block_cyclic(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout

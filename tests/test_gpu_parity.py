@@ -270,3 +270,32 @@ def test_full_size_properties_c3(gpk):
     finally:
         gpk.set_option("nb", 256)
     assert abs(nlml - nlml2) <= 1e-9 * abs(nlml)
+
+
+# ----------------------------------------------------------------------------- multi-GPU logic on one GPU
+@pytest.mark.parametrize("N,P,nb", [(700, 2, 128), (1500, 2, 256), (1500, 3, 256), (2048, 4, 256), (2500, 8, 128), (3000, 8, 256)])
+def test_block_cyclic_cholesky_emulated_ranks(gpk, N, P, nb):
+    """P "virtual ranks" in one process run the production ownership / local-column /
+    cyclic-GEMM-map code; only the RCCL broadcast is replaced by a device copy.  The factor must equal the
+    1-rank factor with the same panel width bit for bit (same kernels, same summation order) and NumPy's."""
+    rng = np.random.RandomState(N + P)
+    Q = rng.randn(N, N)
+    A = Q @ Q.T + N * np.eye(N)
+    gpk.set_option("nb", nb)
+    try:
+        L1 = np.empty((N, N))
+        assert gpk.lib().gpk_test_dist_potrf(_ptr(A), N, 1, _ptr(L1)) == 0, gpk.last_error()
+        LP = np.empty((N, N))
+        assert gpk.lib().gpk_test_dist_potrf(_ptr(A), N, P, _ptr(LP)) == 0, gpk.last_error()
+    finally:
+        gpk.set_option("nb", 256)
+    Lr = np.linalg.cholesky(A)
+    np.testing.assert_allclose(L1, Lr, rtol=1e-11, atol=1e-11 * np.abs(Lr).max())
+    np.testing.assert_array_equal(LP, L1)
+
+
+def test_block_cyclic_not_positive_definite(gpk):
+    A = np.eye(900) * 3.0
+    A[700, 700] = -1.0
+    L = np.empty((900, 900))
+    assert gpk.lib().gpk_test_dist_potrf(_ptr(A), 900, 4, _ptr(L)) == 701
