@@ -10,8 +10,8 @@ synthetic inputs, with X, y, Z already resident in HBM when the timed region sta
         --master-port P bench.py --gpus N --steps K --warmup W
 
 N > 1: the SAME N=16384 posterior is sharded (block-cyclic panels, RCCL panel broadcast over xGMI):
-total work fixed -> "scaling": "strong".  torch.distributed (gloo) is used only to ferry the
-ncclUniqueId and for the final max-over-ranks; all compute is in libgpk.so.
+total work fixed -> "scaling": "strong".  The launcher only provides RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*;
+the ncclUniqueId travels over a TCP socket, barriers and the max over ranks go through RCCL.
 """
 import argparse
 import ctypes
@@ -77,9 +77,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=16384)
-    ap.add_argument("--d", type=int, default=8)
-    ap.add_argument("--m", type=int, default=1024)
+    ap.add_argument("--train-n", dest="n", type=int, default=16384)
+    ap.add_argument("--dim", dest="d", type=int, default=8)
+    ap.add_argument("--test-m", dest="m", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -88,12 +88,10 @@ def main():
     rank, local, world = dist.env_rank()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    pg = None
-    if world > 1:
-        import torch.distributed as tdist
-
-        tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        pg = tdist
+    # One process per GPU (torch.distributed.run only provides RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).
+    # The ncclUniqueId travels over a plain TCP socket, barriers and the max-over-ranks go through RCCL:
+    # torch is never imported (importing it first would also shadow ROCm's librccl/libamdhip64 with the
+    # copies bundled in the torch wheel).
     dist.init_comm(rank, world, device=local)
     l = _lib.lib()
     N, d, M = args.n, args.d, args.m
@@ -107,8 +105,7 @@ def main():
 
     # barrier + device sync on both sides of the timed region (gpk_bench_posterior stages the inputs,
     # runs `warmup` untimed steps, then times exactly `steps` steps with HIP events on its stream).
-    if pg:
-        pg.barrier()
+    _lib.check(l.gpk_comm_barrier(), "barrier")
     _lib.check(l.gpk_sync(), "sync")
     t0 = time.perf_counter()
     rc = l.gpk_bench_posterior(X.ctypes.data_as(P), y.ctypes.data_as(P), N, d, lh.ctypes.data_as(P),
@@ -118,13 +115,11 @@ def main():
     _lib.check(l.gpk_sync(), "sync")
     wall = time.perf_counter() - t0
     t_ms = ms.value
-    if pg:
-        import torch
-
-        tt = torch.tensor([t_ms], dtype=torch.float64)
-        pg.all_reduce(tt, op=pg.ReduceOp.MAX)
+    _lib.check(l.gpk_comm_barrier(), "barrier")
+    if world > 1:
+        tt = (ctypes.c_double * 1)(t_ms)
+        _lib.check(l.gpk_comm_allreduce_max(tt, 1), "allreduce_max")
         t_ms = float(tt[0])
-        pg.barrier()
 
     def stage(name):
         a, c = ctypes.c_double(), ctypes.c_double()
@@ -177,9 +172,8 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, d, M)
         print(json.dumps(out))
-    if pg:
-        pg.barrier()
-        pg.destroy_process_group()
+    _lib.check(l.gpk_comm_barrier(), "barrier")
+    l.gpk_comm_destroy()
 
 
 if __name__ == "__main__":

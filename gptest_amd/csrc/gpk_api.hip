@@ -282,28 +282,12 @@ int gpk_predict(gpk_model* m, const double* Z, int M, double* mean_out, double* 
   if (!m->has_y) return gpk_set_err(-1, "gpk_predict: model was fitted without targets");
   if (M < 1) return gpk_set_err(-1, "gpk_predict: M=%d must be >= 1", M);
   hipStream_t s = G.s_main;
-  const int Mpad = round_up(M, 128);
-  double *dZ = nullptr, *dR = nullptr, *dV = nullptr, *dmv = nullptr;
-  const size_t szR = (size_t)Mpad * m->Npad;
+  double* dZ = nullptr;
+  GPK_TRY(dev_alloc_t(&dZ, (size_t)M * m->d));
   int rc = 0;
-  rc |= dev_alloc_t(&dZ, (size_t)M * m->d);
-  rc |= dev_alloc_t(&dR, szR);
-  rc |= dev_alloc_t(&dV, szR);
-  rc |= dev_alloc_t(&dmv, (size_t)2 * Mpad);
-  if (!rc) {
-    do {
-      if (hipMemcpyAsync(dZ, Z, (size_t)M * m->d * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-      rc = predict_device(m, dZ, M, Mpad, dR, dV, dmv, dmv + Mpad);
-      if (rc) break;
-      if (hipMemcpyAsync(mean_out, dmv, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-      if (hipMemcpyAsync(var_out, dmv + Mpad, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-      if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "predict: %s", hipGetErrorString(hipGetLastError())); break; }
-    } while (0);
-  }
-  if (dZ) dev_free(dZ, (size_t)M * m->d * 8);
-  if (dR) dev_free(dR, szR * 8);
-  if (dV) dev_free(dV, szR * 8);
-  if (dmv) dev_free(dmv, (size_t)2 * Mpad * 8);
+  if (hipMemcpyAsync(dZ, Z, (size_t)M * m->d * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
+  if (!rc) rc = predict_sharded(m, dZ, M, mean_out, var_out);
+  dev_free(dZ, (size_t)M * m->d * 8);
   return rc;
 }
 
@@ -440,14 +424,9 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
   gpk_model* m = nullptr;
   GPK_TRY(model_create(&m, N, d, false));
   hipStream_t s = G.s_main;
-  const int Mpad = round_up(M, 128);
-  const size_t szR = (size_t)Mpad * m->Npad;
-  double *dZ = nullptr, *dR = nullptr, *dV = nullptr, *dmv = nullptr;
+  double* dZ = nullptr;
   int rc = decode_hyp(log_hyp, d, 0.0, m);
   rc |= dev_alloc_t(&dZ, (size_t)M * d);
-  rc |= dev_alloc_t(&dR, szR);
-  rc |= dev_alloc_t(&dV, szR);
-  rc |= dev_alloc_t(&dmv, (size_t)2 * Mpad);
   std::vector<double> hm(M), hv(M);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (!rc) {
@@ -471,11 +450,8 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
         }
         rc = fit_device(m);  // includes the 16-byte scalar read-back (the result of compute_likelihood)
         if (rc) break;
-        rc = predict_device(m, dZ, M, Mpad, dR, dV, dmv, dmv + Mpad);
+        rc = predict_sharded(m, dZ, M, hm.data(), hv.data());  // includes the result read-back
         if (rc) break;
-        if (hipMemcpyAsync(hm.data(), dmv, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-        if (hipMemcpyAsync(hv.data(), dmv + Mpad, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-        if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "bench: %s", hipGetErrorString(hipGetLastError())); break; }
       }
       G.timing = saved_timing;
       if (rc) break;
@@ -492,9 +468,6 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   if (dZ) dev_free(dZ, (size_t)M * d * 8);
-  if (dR) dev_free(dR, szR * 8);
-  if (dV) dev_free(dV, szR * 8);
-  if (dmv) dev_free(dmv, (size_t)2 * Mpad * 8);
   if (rc > 0) gpk_set_err(rc, "kernel matrix is not positive definite (leading minor %d)", rc);
   model_destroy(m);
   return rc;

@@ -21,6 +21,13 @@ int comm_bcast(double* buf, size_t count, int root, hipStream_t s) {
   return 0;
 }
 
+// every rank contributes `count` doubles; recv holds nranks*count
+int comm_allgather(const double* send, double* recv, size_t count, hipStream_t s) {
+  if (G.nranks <= 1) return 0;
+  GPK_NCCL(ncclAllGather(send, recv, count, ncclDouble, (ncclComm_t)G.nccl, s));
+  return 0;
+}
+
 extern "C" {
 
 int gpk_comm_unique_id(void* out128) {

@@ -87,6 +87,10 @@ int factor_panel(gpk_model* m, int p, hipStream_t s);          // owner only
 int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hipStream_t s);
 int dist_update(gpk_model* m, int p, int first_block, int nblocks_max, hipStream_t s);  // cyclic trailing update
 int comm_bcast(double* buf, size_t count, int root, hipStream_t s);
+int comm_allgather(const double* send, double* recv, size_t count, hipStream_t s);
+// prediction for M test points resident at dZ: sharded over the ranks when P > 1 (each rank solves M/P
+// right-hand sides, results all-gathered); dmv_out receives mean[0:M] at [0] and var[0:M] at [Mtot]
+int predict_sharded(gpk_model* m, const double* dZ, int M, double* h_mean, double* h_var);
 int trsv_forward(gpk_model* m, double* v);                      // v <- L^-1 v  (Npad vector)
 int trsv_backward(gpk_model* m, double* v);                     // v <- L^-T v
 int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, double* dV, double* dmean, double* dvar);

@@ -570,3 +570,54 @@ int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, 
   timer_end("predict", s);
   return 0;
 }
+
+// ------------------------------------------------------------------ prediction entry shared by gpk_predict / bench
+int predict_sharded(gpk_model* m, const double* dZ, int M, double* h_mean, double* h_var) {
+  hipStream_t s = G.s_main;
+  const int P = (m->P > 1 && !m->virtual_rank) ? m->P : 1;
+  const int Mc = (M + P - 1) / P;             // test points per rank
+  const int m0 = (P > 1) ? m->r * Mc : 0;
+  int cnt = M - m0;
+  if (cnt > Mc) cnt = Mc;
+  if (cnt < 0) cnt = 0;
+  const int Mpad = round_up(Mc, 128);
+  const size_t szR = (size_t)Mpad * m->Npad;
+  double *dR = nullptr, *dV = nullptr, *dloc = nullptr, *dall = nullptr;
+  int rc = 0;
+  rc |= dev_alloc_t(&dR, szR);
+  rc |= dev_alloc_t(&dV, szR);
+  rc |= dev_alloc_t(&dloc, (size_t)2 * Mpad);
+  rc |= dev_alloc_t(&dall, (size_t)2 * Mpad * P);
+  std::vector<double> hall((size_t)2 * Mpad * P);
+  if (!rc) {
+    do {
+      if (hipMemsetAsync(dloc, 0, (size_t)2 * Mpad * 8, s) != hipSuccess) { rc = gpk_set_err(-2, "memset failed"); break; }
+      if (cnt > 0) {
+        rc = predict_device(m, dZ + (size_t)m0 * m->d, cnt, round_up(cnt, 128), dR, dV, dloc, dloc + Mpad);
+        if (rc) break;
+      }
+      const double* src = dloc;
+      if (P > 1) {
+        rc = comm_allgather(dloc, dall, (size_t)2 * Mpad, s);
+        if (rc) break;
+        src = dall;
+      }
+      if (hipMemcpyAsync(hall.data(), src, (size_t)2 * Mpad * P * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+      if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "predict: %s", hipGetErrorString(hipGetLastError())); break; }
+      for (int q = 0; q < P; ++q) {
+        const int q0 = q * Mc;
+        int qc = M - q0;
+        if (qc > Mc) qc = Mc;
+        for (int i = 0; i < qc; ++i) {
+          h_mean[q0 + i] = hall[(size_t)q * 2 * Mpad + i];
+          h_var[q0 + i] = hall[(size_t)q * 2 * Mpad + Mpad + i];
+        }
+      }
+    } while (0);
+  }
+  if (dR) dev_free(dR, szR * 8);
+  if (dV) dev_free(dV, szR * 8);
+  if (dloc) dev_free(dloc, (size_t)2 * Mpad * 8);
+  if (dall) dev_free(dall, (size_t)2 * Mpad * P * 8);
+  return rc;
+}

@@ -2,8 +2,9 @@
 
 libgpk.so owns the RCCL communicator (panel broadcasts happen inside the factorisation, in C++);
 the host only has to hand every rank the same 128-byte ncclUniqueId.  ``bootstrap`` is any
-callable ``bytes|None -> bytes`` that broadcasts rank 0's bytes to all ranks; ``torch_bootstrap``
-does it over a torch.distributed (gloo) process group -- torch is plumbing here, never compute.
+callable ``bytes|None -> bytes`` that broadcasts rank 0's bytes to all ranks: ``socket_bootstrap`` (default,
+plain TCP next to the launcher's MASTER_PORT, no torch anywhere) or ``torch_bootstrap`` (an existing
+torch.distributed process group).  Barriers and max-reductions go through RCCL itself.
 """
 import ctypes
 import os
@@ -44,7 +45,52 @@ def torch_bootstrap(payload):
     return bytes(t.tolist())
 
 
-def init_comm(rank, world, bootstrap=torch_bootstrap, device=None):
+def socket_bootstrap(payload, rank=None, world=None, timeout=120.0):
+    """Broadcast rank 0's bytes over plain TCP (no torch in the product path).  Rank 0 listens next to the
+    launcher's rendezvous port (MASTER_PORT + 7919), the other ranks connect with retries."""
+    import socket
+    import time
+
+    if rank is None or world is None:
+        rank, _, world = env_rank()
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = (int(os.environ.get("MASTER_PORT", "29500")) + 7919) % 65536
+    if port < 1024:
+        port += 20000
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((host, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        try:
+            for _ in range(world - 1):
+                c, _addr = srv.accept()
+                c.sendall(payload)
+                c.close()
+        finally:
+            srv.close()
+        return payload
+    deadline = time.time() + timeout
+    while True:
+        try:
+            c = socket.create_connection((host, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise
+            time.sleep(0.05)
+    buf = b""
+    while len(buf) < UID_BYTES:
+        chunk = c.recv(UID_BYTES - len(buf))
+        if not chunk:
+            break
+        buf += chunk
+    c.close()
+    return buf
+
+
+def init_comm(rank, world, bootstrap=socket_bootstrap, device=None):
     """Bind to the GPU, create the RCCL communicator inside libgpk.so."""
     _lib.init(device)
     l = _lib.lib()

@@ -68,13 +68,42 @@ WORKER = textwrap.dedent(
 def test_two_rank_gloo_block_cyclic(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    for attempt in range(3):  # the free-port probe can race with another process: retry on a new port
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), str(script)]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        if out.returncode == 0:
+            break
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_socket_bootstrap_two_processes(tmp_path):
+    """The default unique-id ferry (plain TCP, no torch): two real processes."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(script)]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    code = textwrap.dedent(
+        """
+        import os, sys
+        sys.path.insert(0, %r)
+        from gptest_amd import dist
+        rank = int(os.environ["RANK"])
+        got = dist.socket_bootstrap(bytes(range(128)) if rank == 0 else None)
+        assert got == bytes(range(128))
+        print("ok", rank)
+        """
+    ) % ROOT
+    procs = []
+    for r in (0, 1):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, o + e
