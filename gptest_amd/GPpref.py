@@ -1,0 +1,166 @@
+"""Drop-in for the reference's ``GPpref.py`` (preference GP, Laplace approximation) on the MI355X core.
+
+Same public surface as osurdml/GPtest ``GPpref.py``: ``PrefProbit`` (GPpref.py:46-94),
+``PreferenceGaussianProcess(x_train, uvi_train, y_train, likelihood=PrefProbit, delta_f=1e-6)`` with
+``calc_laplace(loghyp, f=None) -> (f (nx,1), lml)`` and ``calc_nlml(loghyp)`` (GPpref.py:96-161),
+``squared_distance`` (GPpref.py:13-22), ``std_norm_pdf`` (GPpref.py:8-10).  Runs under Python 3 and does
+not need GPy: the kernel matrix ``GPy.kern.RBF(ARD=True).K`` (call sites GPpref.py:109,122) is the same
+``variance * exp(-0.5 * sum_k ((x_ik - x_jk)/l_k)^2)`` that ``gpk_fit`` builds on the GPU.
+
+What runs where
+* K + eps*I, its Cholesky, logdetK and every Newton iteration (GPpref.py:122-155): libgpk.so
+  (``gpk_fit`` with the keep-K flag, then ``gpk_pref_laplace``).  The reference forms the explicit inverse
+  ``iK`` and ``inv(iK + W)`` (2 nx^3 per iteration); the GPU path never inverts K (see k_pref.hip).
+* ``PrefProbit`` keeps its NumPy methods for API compatibility (``derivatives`` still returns the dense W
+  the reference returns), but ``calc_laplace`` does not call them.
+
+Reference quirks kept for parity: probit sigma stays at the constructor default because
+``self.likelihood.set_sigma = ...`` (GPpref.py:115) assigns over the method; ``logdetK`` is
+``sum(log(diag L))`` (GPpref.py:131) and ``log_marginal`` halves it again (GPpref.py:93); the Cholesky is
+retried with 10x jitter on ``LinAlgError`` (GPpref.py:126-135).  Parity for this module is UNPINNED (the
+reference cannot be imported: Python-2 + GPy); tests compare against ``oracle/gppref_oracle.py``.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .GPr import fit_handle, squared_distance  # noqa: F401  (squared_distance: GPpref.py:13-22)
+
+__all__ = ["std_norm_pdf", "squared_distance", "PrefProbit", "PreferenceGaussianProcess"]
+
+_sqrt_2pi = np.sqrt(2 * np.pi)
+
+
+def std_norm_cdf(x):
+    from scipy.special import ndtr
+
+    return ndtr(x)
+
+
+def std_norm_pdf(x):
+    """GPpref.py:8-10."""
+    x = np.clip(x, -1e150, 1e150)
+    return np.exp(-(x ** 2) / 2) / _sqrt_2pi
+
+
+class PrefProbit(object):
+    """GPpref.py:46-94 (host NumPy; small vectors)."""
+
+    def __init__(self, sigma=1.0):
+        self.set_sigma(sigma)
+        self.log2pi = np.log(2.0 * np.pi)
+
+    def set_sigma(self, sigma):
+        self.sigma = sigma
+        self._isqrt2sig = 1.0 / (self.sigma * np.sqrt(2.0))
+        self._i2var = self._isqrt2sig ** 2
+
+    def z_k(self, uvi, f, y):
+        zc = self._isqrt2sig * (f[uvi[:, 1]] - f[uvi[:, 0]])
+        return y * zc
+
+    def I_k(self, x, uv):
+        if x == uv[0]:
+            return -1
+        elif x == uv[1]:
+            return 1
+        return 0
+
+    def derivatives(self, uvi, y, f):
+        """Dense (W, dpy_df) exactly as GPpref.py:68-88 returns them (vectorised scatter instead of the loop)."""
+        nx = len(f)
+        z = self.z_k(uvi, f, y)
+        phi_z = std_norm_cdf(z)
+        N_z = std_norm_pdf(z)
+        dpy_df = np.zeros((nx, 1), dtype="float")
+        dpyuv_df = y * self._isqrt2sig * N_z / phi_z
+        dpy_df[uvi[:, 0]] += -dpyuv_df
+        dpy_df[uvi[:, 1]] += dpyuv_df
+        inner = (-self._i2var * (z * N_z / phi_z + (N_z / phi_z) ** 2)).reshape(-1)
+        W = np.zeros((nx, nx), dtype="float")
+        u, v = uvi[:, 0], uvi[:, 1]
+        np.subtract.at(W, (u, u), inner)
+        np.subtract.at(W, (v, v), inner)
+        np.add.at(W, (u, v), inner)
+        np.add.at(W, (v, u), inner)
+        return W, dpy_df
+
+    def log_marginal(self, uvi, y, f, iK, logdetK):
+        z = self.z_k(uvi, f, y)
+        phi_z = std_norm_cdf(z)
+        psi = (np.sum(np.log(phi_z)) - 0.5 * np.matmul(np.matmul(f.T, iK), f)
+               - 0.5 * logdetK - iK.shape[0] / 2.0 * self.log2pi)
+        return psi.flat[0]
+
+
+class _RBFParams(object):
+    """Stand-in for the two GPy kernel attributes the reference sets (GPpref.py:113-114)."""
+
+    def __init__(self, dim):
+        self.lengthscale = np.ones(dim)
+        self.variance = 1.0
+
+
+class PreferenceGaussianProcess(object):
+    """GPpref.py:96-161."""
+
+    def __init__(self, x_train, uvi_train, y_train, likelihood=PrefProbit, delta_f=1e-6):
+        self._xdim = x_train.shape[1]
+        self._nx = x_train.shape[0]
+        self.x_train = x_train
+        self.y_train = y_train
+        self.uvi_train = uvi_train
+        self.delta_f = delta_f
+        self.likelihood = likelihood()
+        self.kern = _RBFParams(self._xdim)
+        self.max_iter = 100      # the reference loops without a bound (GPpref.py:140)
+        self.verbose = False     # the reference prints f_error, lml every iteration (GPpref.py:154)
+        self.last_iterations = 0
+        self.last_eps = None
+        self.last_trace = None
+
+    def calc_laplace(self, loghyp, f=None):
+        """GPpref.py:112-157 -> (f (nx,1), lml)."""
+        loghyp = np.asarray(loghyp, dtype=np.float64)
+        self.kern.lengthscale = np.exp(loghyp[0:self._xdim])
+        self.kern.variance = (np.exp(loghyp[self._xdim])) ** 2
+        self.likelihood.set_sigma = np.exp(loghyp[-1])  # GPpref.py:115, verbatim: sigma itself is unchanged
+        if f is None:
+            f = np.zeros((self._nx, 1))
+        # K = variance * exp(-r^2/2), no noise term: log sigma_n = -inf; jitter eps on the diagonal
+        lh = np.concatenate([loghyp[0:self._xdim], [loghyp[self._xdim]], [-np.inf]])
+        eps = 1e-6
+        while True:
+            try:
+                handle, _ = fit_handle(self.x_train, None, lh, jitter=eps, keep_k=True)
+                break
+            except np.linalg.LinAlgError:
+                eps = eps * 10
+                if self.verbose:
+                    print("Inversion issue, adding noise: {0}".format(eps))
+        self.last_eps = eps
+        uvi = np.ascontiguousarray(self.uvi_train, dtype=np.int64)
+        y = np.ascontiguousarray(np.asarray(self.y_train, dtype=np.float64).reshape(-1))
+        fv = np.ascontiguousarray(np.asarray(f, dtype=np.float64).reshape(-1)).copy()
+        if uvi.shape != (len(y), 2) or len(fv) != self._nx:
+            raise ValueError("uvi_train must be (npairs,2), y_train (npairs,1), f (nx,1)")
+        lml = ctypes.c_double()
+        iters = ctypes.c_int()
+        trace = np.zeros(self.max_iter)
+        rc = _lib.lib().gpk_pref_laplace(handle.ptr, uvi.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+                                         y.ctypes.data_as(_lib.c_double_p), len(y), float(self.likelihood.sigma),
+                                         fv.ctypes.data_as(_lib.c_double_p), float(self.delta_f), int(self.max_iter),
+                                         ctypes.byref(lml), ctypes.byref(iters), trace.ctypes.data_as(_lib.c_double_p))
+        _lib.check(rc, "gpk_pref_laplace")
+        self.last_iterations = iters.value
+        self.last_trace = trace[:iters.value].copy()
+        if self.verbose:
+            for e in self.last_trace:
+                print(e)
+        return fv.reshape(self._nx, 1), lml.value
+
+    def calc_nlml(self, loghyp):
+        """GPpref.py:159-161."""
+        f, lml = self.calc_laplace(loghyp)
+        return -lml

@@ -89,3 +89,15 @@ int launch_transpose(const double* in, long ldin, int rows, int cols, double* ou
 int launch_fill(double* p, size_t n, double v, hipStream_t s);
 int launch_unpack_L(const double* Lp, int w, int h, int c0, double* out, long ldout, hipStream_t s);
 int launch_gather2d(const double* K, long ldk, const long long* idx, int nidx, double* out, hipStream_t s);
+
+// ---------------------------------------------------------------- preference-GP Laplace kernels (k_pref.hip)
+int launch_pref_pair_stats(const long long* uvi, const double* y, const double* f, int npairs, double isq, double* z,
+                           double* q, double* c, double* logphi, hipStream_t s);
+int launch_pref_pair_t(const long long* uvi, const double* f, const double* c, const double* q, int npairs, double* t, hipStream_t s);
+int launch_pref_scatter(const long long* uvi, const double* t, const double* scale, int do_sqrt, int npairs, double* out, hipStream_t s);
+int launch_pref_gather(const long long* uvi, const double* x, const double* c, int npairs, double* r, hipStream_t s);
+int launch_pref_build_S(const double* K, long ldk, const long long* uvi, int npairs, double* S, long lds_, hipStream_t s);
+int launch_pref_build_B(const double* S, long lds_, const double* c, int npairs, int npad, double* B, long ldb, hipStream_t s);
+int launch_maxabsdiff(const double* a, const double* b, int n, double* out, hipStream_t s);
+int launch_sum(const double* a, int n, double* out, hipStream_t s);
+int launch_sub(const double* a, const double* b, int n, double* out, hipStream_t s);

@@ -1,0 +1,116 @@
+// Host driver of the preference-GP Laplace loop (PreferenceGaussianProcess.calc_laplace, GPpref.py:112-157)
+// on top of a fitted model handle (K + eps*I factored, unfactored copy kept).  Everything stays in HBM;
+// per Newton iteration the host sees one scalar (max |f_new - f|).
+#include "../../include/gpk.h"
+#include "gpk_core.h"
+#include <cmath>
+
+extern "C" int gpk_pref_laplace(gpk_model* m, const long long* uvi, const double* y, int npairs, double sigma,
+                                double* f_inout, double delta_f, int max_iter, double* lml_out, int* iters_out,
+                                double* ferr_trace) {
+  GPK_TRY(rt_require());
+  if (!m || !uvi || !y || !f_inout) return gpk_set_err(-1, "gpk_pref_laplace: null pointer");
+  if (!m->dKcopy) return gpk_set_err(-1, "gpk_pref_laplace: fit the model with the keep-K flag");
+  if (m->P != 1) return gpk_set_err(-1, "gpk_pref_laplace: single-GPU models only");
+  if (npairs < 1 || max_iter < 1 || !(sigma > 0.0)) return gpk_set_err(-1, "gpk_pref_laplace: bad arguments");
+  const int nx = m->N, np_ = m->Npad;
+  for (int i = 0; i < 2 * npairs; ++i)
+    if (uvi[i] < 0 || uvi[i] >= nx) return gpk_set_err(-1, "gpk_pref_laplace: pair index %lld outside 0..%d", uvi[i], nx - 1);
+  hipStream_t s = G.s_main;
+  gpk_model* mb = nullptr;  // the npairs x npairs system B = I + C^1/2 (D K D^T) C^1/2
+  GPK_TRY(model_create(&mb, npairs, 1, false, 1, 0));
+  const int nbp = mb->Npad;
+  long long* duvi = nullptr;
+  double *dy = nullptr, *df = nullptr, *dfn = nullptr, *dq = nullptr, *dc = nullptr, *dlp = nullptr, *dt = nullptr,
+         *dr = nullptr, *db = nullptr, *dkb = nullptr, *dsv = nullptr, *dks = nullptr, *dS = nullptr, *dscal = nullptr;
+  int rc = 0;
+  rc |= dev_alloc_t(&duvi, (size_t)2 * npairs);
+  rc |= dev_alloc_t(&dy, (size_t)npairs);
+  rc |= dev_alloc_t(&df, (size_t)np_);
+  rc |= dev_alloc_t(&dfn, (size_t)np_);
+  rc |= dev_alloc_t(&dq, (size_t)npairs);
+  rc |= dev_alloc_t(&dc, (size_t)npairs);
+  rc |= dev_alloc_t(&dlp, (size_t)npairs);
+  rc |= dev_alloc_t(&dt, (size_t)npairs);
+  rc |= dev_alloc_t(&dr, (size_t)nbp);
+  rc |= dev_alloc_t(&db, (size_t)np_);
+  rc |= dev_alloc_t(&dkb, (size_t)np_);
+  rc |= dev_alloc_t(&dsv, (size_t)np_);
+  rc |= dev_alloc_t(&dks, (size_t)np_);
+  rc |= dev_alloc_t(&dS, (size_t)npairs * nbp);
+  rc |= dev_alloc_t(&dscal, 8);
+  const double isq = 1.0 / (sigma * std::sqrt(2.0));
+  int iters = 0;
+  double lml = 0.0;
+#define PREF_HIP(x)                                                                         \
+  if (!rc && (x) != hipSuccess) rc = gpk_set_err(-2, "%s failed: %s", #x, hipGetErrorString(hipGetLastError()))
+#define PREF_DO(x) \
+  if (!rc) rc = (x)
+  PREF_HIP(hipMemcpyAsync(duvi, uvi, (size_t)2 * npairs * 8, hipMemcpyHostToDevice, s));
+  PREF_HIP(hipMemcpyAsync(dy, y, (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+  PREF_HIP(hipMemsetAsync(df, 0, (size_t)np_ * 8, s));
+  PREF_HIP(hipMemcpyAsync(df, f_inout, (size_t)nx * 8, hipMemcpyHostToDevice, s));
+  PREF_HIP(hipMemsetAsync(dfn, 0, (size_t)np_ * 8, s));
+  PREF_DO(launch_pref_build_S(m->dKcopy, np_, duvi, npairs, dS, nbp, s));
+  for (int it = 0; it < max_iter && !rc; ++it) {
+    PREF_DO(launch_pref_pair_stats(duvi, dy, df, npairs, isq, nullptr, dq, dc, nullptr, s));
+    PREF_DO(launch_pref_pair_t(duvi, df, dc, dq, npairs, dt, s));
+    PREF_HIP(hipMemsetAsync(db, 0, (size_t)np_ * 8, s));
+    PREF_DO(launch_pref_scatter(duvi, dt, nullptr, 0, npairs, db, s));            // b = W f + grad
+    PREF_DO(launch_gemv(m->dKcopy, np_, np_, np_, db, dkb, 1.0, 0.0, s));          // K b
+    PREF_HIP(hipMemsetAsync(dr, 0, (size_t)nbp * 8, s));
+    PREF_DO(launch_pref_gather(duvi, dkb, dc, npairs, dr, s));                     // C^1/2 D K b
+    PREF_DO(launch_pref_build_B(dS, nbp, dc, npairs, nbp, mb->dK, mb->ldk, s));
+    PREF_DO(potrf_device(mb));
+    PREF_DO(trsv_forward(mb, dr));
+    PREF_DO(trsv_backward(mb, dr));                                               // B^-1 (...)
+    PREF_HIP(hipMemsetAsync(dsv, 0, (size_t)np_ * 8, s));
+    PREF_DO(launch_pref_scatter(duvi, dr, dc, 1, npairs, dsv, s));                 // D^T C^1/2 x
+    PREF_DO(launch_gemv(m->dKcopy, np_, np_, np_, dsv, dks, 1.0, 0.0, s));
+    PREF_DO(launch_sub(dkb, dks, np_, dfn, s));                                    // f_new
+    PREF_DO(launch_maxabsdiff(dfn, df, nx, dscal, s));
+    double ferr = 0.0;
+    int binfo = 0;
+    PREF_HIP(hipMemcpyAsync(&ferr, dscal, 8, hipMemcpyDeviceToHost, s));
+    PREF_HIP(hipMemcpyAsync(&binfo, mb->dinfo, 4, hipMemcpyDeviceToHost, s));
+    PREF_HIP(hipStreamSynchronize(s));
+    if (!rc && binfo > 0) rc = gpk_set_err(-4, "Newton system lost positive definiteness (minor %d)", binfo);
+    if (rc) break;
+    std::swap(df, dfn);
+    iters = it + 1;
+    if (ferr_trace) ferr_trace[it] = ferr;
+    if (!(ferr > delta_f)) break;  // GPpref.py:140: while f_error > delta_f
+  }
+  // lml at the final f (GPpref.py:90-94, 144): sum log Phi(z) - f^T iK f / 2 - logdetK/2 - nx/2 log 2 pi
+  double hs[2] = {0, 0};
+  PREF_DO(launch_pref_pair_stats(duvi, dy, df, npairs, isq, nullptr, nullptr, nullptr, dlp, s));
+  PREF_DO(launch_sum(dlp, npairs, dscal, s));
+  PREF_HIP(hipMemcpyAsync(dks, df, (size_t)np_ * 8, hipMemcpyDeviceToDevice, s));
+  PREF_DO(trsv_forward(m, dks));
+  PREF_DO(launch_dot(dks, dks, np_, dscal + 1, s));
+  PREF_HIP(hipMemcpyAsync(hs, dscal, 16, hipMemcpyDeviceToHost, s));
+  PREF_HIP(hipMemcpyAsync(f_inout, df, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+  PREF_HIP(hipStreamSynchronize(s));
+  if (!rc) lml = hs[0] - 0.5 * hs[1] - 0.5 * m->logdet - 0.5 * nx * std::log(2.0 * M_PI);
+  if (lml_out) *lml_out = lml;
+  if (iters_out) *iters_out = iters;
+#undef PREF_HIP
+#undef PREF_DO
+  dev_free(duvi, (size_t)2 * npairs * 8);
+  dev_free(dy, (size_t)npairs * 8);
+  dev_free(df, (size_t)np_ * 8);
+  dev_free(dfn, (size_t)np_ * 8);
+  dev_free(dq, (size_t)npairs * 8);
+  dev_free(dc, (size_t)npairs * 8);
+  dev_free(dlp, (size_t)npairs * 8);
+  dev_free(dt, (size_t)npairs * 8);
+  dev_free(dr, (size_t)nbp * 8);
+  dev_free(db, (size_t)np_ * 8);
+  dev_free(dkb, (size_t)np_ * 8);
+  dev_free(dsv, (size_t)np_ * 8);
+  dev_free(dks, (size_t)np_ * 8);
+  dev_free(dS, (size_t)npairs * nbp * 8);
+  dev_free(dscal, 64);
+  model_destroy(mb);
+  return rc;
+}

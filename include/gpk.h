@@ -90,6 +90,15 @@ int gpk_model_scalar(gpk_model* h, int which, double* out);
 int gpk_model_get_L(gpk_model* h, double* L_out);
 int gpk_free(gpk_model* h);
 
+/* PreferenceGaussianProcess.calc_laplace, Newton loop + PrefProbit.derivatives/log_marginal
+ * (GPpref.py:137-157, 56-94) on a model fitted with flags bit0 (K + eps*I factored, copy kept).
+ * uvi: (npairs,2) int64 row-major indices into the training points, y: +-1 labels, sigma: probit noise
+ * (the reference always ends up with 1.0, GPpref.py:115), f_inout: (nx) start / mode, ferr_trace: optional
+ * max_iter doubles (max|f_new - f| per iteration).  Stops when max|df| <= delta_f or after max_iter. */
+int gpk_pref_laplace(gpk_model* h, const long long* uvi, const double* y, int npairs, double sigma,
+                     double* f_inout, double delta_f, int max_iter, double* lml_out, int* iters_out,
+                     double* ferr_trace);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------- */
 /* HIP-event timings (ms) of the stages of the last gpk_fit / gpk_predict on this
  * process; names: "kbuild","potrf","trailing","panel","solve_y","predict".      */

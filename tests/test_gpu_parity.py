@@ -299,3 +299,62 @@ def test_block_cyclic_not_positive_definite(gpk):
     A[700, 700] = -1.0
     L = np.empty((900, 900))
     assert gpk.lib().gpk_test_dist_potrf(_ptr(A), 900, 4, _ptr(L)) == 701
+
+
+# ----------------------------------------------------------------------------- preference GP (GPpref.py)
+def test_gppref_seeded_demo_matches_oracle(gpk):
+    """GP_preference_demo.py:7-44,60-67 inputs.  PARITY UNPINNED (the reference needs Python 2 + GPy): the
+    oracle is the restatement oracle/gppref_oracle.py, which reproduces the SURVEY 8c trace."""
+    from gptest_amd import GPpref
+    from oracle import gppref_oracle as po
+
+    x, uvi, y = po.demo_problem()
+    lh = np.log([0.1, 1.0, 0.1])
+    gp = GPpref.PreferenceGaussianProcess(x, uvi, y, delta_f=1e-5)
+    f, lml = gp.calc_laplace(lh)
+    tr = []
+    fo, lo, it, eps = po.calc_laplace(x, uvi, y, lh, delta_f=1e-5, trace=tr)
+    assert f.shape == (40, 1)
+    assert gp.last_iterations == it == 5 and gp.last_eps == eps == 1e-6
+    np.testing.assert_allclose(f, fo, rtol=1e-6, atol=1e-6 * np.abs(fo).max())
+    assert abs(lml - lo) <= 1e-6 * abs(lo)
+    assert lml == pytest.approx(40.5831069552, rel=1e-8)
+    np.testing.assert_allclose(gp.last_trace[:3], [t[0] for t in tr[:3]], rtol=1e-5)
+    assert gp.calc_nlml(lh) == pytest.approx(-lml, rel=1e-12)
+
+
+@pytest.mark.parametrize("nx,d", [(300, 2), (1024, 4)])
+def test_gppref_larger_matches_oracle(gpk, nx, d):
+    from gptest_amd import GPpref
+    from oracle import gppref_oracle as po
+
+    x, uvi, y = po.demo_problem(n_train=nx // 2, seed=3, d=d)
+    lh = np.log([0.3] * d + [1.0, 0.1])
+    gp = GPpref.PreferenceGaussianProcess(x, uvi, y, delta_f=1e-6)
+    f, lml = gp.calc_laplace(lh)
+    fo, lo, it, eps = po.calc_laplace(x, uvi, y, lh, delta_f=1e-6)
+    assert gp.last_eps == eps
+    assert abs(gp.last_iterations - it) <= 1
+    np.testing.assert_allclose(f, fo, rtol=0, atol=1e-6 * np.abs(fo).max())
+    assert abs(lml - lo) <= 1e-6 * abs(lo)
+
+
+def test_prefprobit_surface_matches_oracle(gpk):
+    """PrefProbit host methods (GPpref.py:46-94) against the restatement, incl. the dense W."""
+    from gptest_amd import GPpref
+    from oracle import gppref_oracle as po
+
+    rng = np.random.RandomState(2)
+    nx = 30
+    uvi = rng.choice(range(nx), (12, 2), replace=False)
+    y = np.where(rng.rand(12, 1) > 0.5, 1, -1)
+    f = rng.randn(nx, 1)
+    a, b = GPpref.PrefProbit(), po.PrefProbit()
+    Wa, ga = a.derivatives(uvi, y, f)
+    Wb, gb = b.derivatives(uvi, y, f)
+    np.testing.assert_allclose(Wa, Wb, rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(ga, gb, rtol=1e-14)
+    np.testing.assert_allclose(a.z_k(uvi, f, y), b.z_k(uvi, f, y))
+    iK = np.eye(nx)
+    assert a.log_marginal(uvi, y, f, iK, 0.3) == pytest.approx(b.log_marginal(uvi, y, f, iK, 0.3), rel=1e-14)
+    assert a.I_k(3, (3, 4)) == -1 and a.I_k(4, (3, 4)) == 1 and a.I_k(5, (3, 4)) == 0
