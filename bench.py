@@ -141,6 +141,19 @@ def main():
         tr_flops = stage_work("trailing")
         kb_bytes = stage_work("kbuild")
         ach = tr_flops / (tr_ms * 1e-3) / 1e12 if tr_ms > 0 else 0.0
+        # HBM traffic of that kernel per launch: PMC counters cannot be read from inside the process, so the
+        # figure comes from the committed rocprofv3 --pmc passes of this same command (scripts/pmc_traffic.sh)
+        traffic = None
+        traffic_note = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic_gemm_nt8.json")) as fh:
+                tj = json.load(fh)
+            if world == 1 and N == 16384:
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_note = ("PMC FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE, avg over the %d trailing-update launches of one "
+                                "factorisation; algorithmic %.3g B/launch" % (tj["launches"], tj["algorithmic_bytes_per_launch"]))
+        except Exception:
+            pass
         flops = tr_flops / max(args.steps, 1)
         out = {
             "metric": "GP posterior solves/sec (N=16384, d=8, M=1024; fit + predict sharing one Cholesky)",
@@ -157,9 +170,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "GPr regression N=%d d=%d RBF fp64, M=%d test points (BASELINE configs[2])" % (N, d, M),
                        "panel_width": nb, "parallelism": "1 GPU" if world == 1 else "block-cyclic panels x%d, RCCL broadcast" % world},
-            "roofline": {"kernel": "gemm_nt_kernel (Cholesky trailing update, fp64 MFMA 16x16x4)", "bound": "mfma",
+            "roofline": {"kernel": "gemm_nt8_kernel (Cholesky trailing update, fp64 MFMA 16x16x4)", "bound": "mfma",
                          "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "launches": tr_n, "avg_launch_ms": tr_ms / tr_n if tr_n else None,
                          "alg_flops_per_step_in_timed_launches": flops},
             "kbuild": {"kernel": "se_build_kernel", "bound": "hbm", "ms": kb_ms / kb_n if kb_n else None, "unit": "GB/s",

@@ -118,6 +118,19 @@ int gpk_set_option(const char* key, double value) {
     int nb = (int)value;
     if (nb < 128 || nb % 128) return gpk_set_err(-1, "option nb=%d must be a positive multiple of 128", nb);
     G.nb = nb;
+    G.nb_auto = 0;  // an explicit panel width switches the automatic schedule off
+  } else if (k == "nb_auto") {
+    G.nb_auto = (int)value;
+  } else if (k == "nb_big") {
+    if ((int)value < 128 || (int)value % 128) return gpk_set_err(-1, "nb_big must be a multiple of 128");
+    G.nb_big = (int)value;
+  } else if (k == "nb_big_until") {
+    G.nb_big_until = (int)value;
+  } else if (k == "nb_small") {
+    if ((int)value < 128 || (int)value % 128) return gpk_set_err(-1, "nb_small must be a multiple of 128");
+    G.nb_small = (int)value;
+  } else if (k == "nb_small_from") {
+    G.nb_small_from = (int)value;
   } else if (k == "lookahead") {
     G.lookahead = (int)value;
   } else if (k == "gemm_variant") {

@@ -26,6 +26,9 @@ struct Runtime {
   size_t pool_bytes = 0;
   // options
   int nb = 256;
+  // single-GPU panel schedule: wide panels (K = nb_big) while the trailing matrix is large and the panel
+  // chain hides behind the update, nb in the middle, nb_small at the tail where the chain IS the critical path
+  int nb_big = 512, nb_big_until = 8192, nb_small = 128, nb_small_from = 2048, nb_auto = 1;
   int lookahead = 1;
   int timing = 0;
   int xcd_sq = 1;              // XCD-aware 8x8-tile square order in the big GEMMs

@@ -155,12 +155,19 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r) {
   m->Npad = (P > 1) ? round_up(N, nb) : round_up(N, GPK_T);
   m->nT = m->Npad / GPK_T;
   size_t off = 0;
-  for (int c0 = 0; c0 < m->Npad; c0 += nb) {
-    int w = std::min(nb, m->Npad - c0);
+  for (int c0 = 0; c0 < m->Npad;) {
+    int w = nb;
+    if (P == 1 && G.nb_auto) {
+      const int rem = m->Npad - c0;
+      if (rem > G.nb_big_until + G.nb_big) w = G.nb_big;
+      else if (rem <= G.nb_small_from) w = G.nb_small;
+    }
+    w = std::min(w, m->Npad - c0);
     m->pc0.push_back(c0);
     m->pw.push_back(w);
     m->poff.push_back(off);
     off += (size_t)(m->Npad - c0) * w;
+    c0 += w;
   }
   m->nP = (int)m->pc0.size();
   m->L_elems = off;
@@ -179,7 +186,7 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r) {
   rc |= dev_alloc_t(&m->dL, m->L_elems);
   rc |= dev_alloc_t(&m->dDinv, (size_t)m->nT * 128 * 128);
   rc |= dev_alloc_t(&m->dscal, 8);
-  rc |= dev_alloc_t(&m->dws, (size_t)64 * nb);
+  rc |= dev_alloc_t(&m->dws, (size_t)64 * std::max(nb, G.nb_big));
   rc |= dev_alloc_t(&m->dinfo, 4);
   if (rc) {
     model_destroy(m);
@@ -200,7 +207,7 @@ void model_destroy(gpk_model* m) {
   dev_free(m->dL, m->L_elems * 8);
   dev_free(m->dDinv, (size_t)m->nT * 128 * 128 * 8);
   dev_free(m->dscal, 64);
-  dev_free(m->dws, (size_t)64 * m->NB * 8);
+  dev_free(m->dws, (size_t)64 * std::max(m->NB, G.nb_big) * 8);
   dev_free(m->dinfo, 16);
   delete m;
 }
@@ -531,43 +538,89 @@ int fit_device(gpk_model* m) {
 // ------------------------------------------------------------------ prediction (GPr.py:45-54)
 // V = Kzx L^-T by blocked forward substitution on the ROWS of Kzx (the same NT GEMM as the
 // factorisation), then mean_j = V_j . w and var_j = sf2 - |V_j|^2 in one pass.
-int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, double* dV, double* dmean,
-                   double* dvar) {
-  hipStream_t s = G.s_main;
+// forward substitution of panel p's diagonal block on the rows of R:  V[:, panel p] = R[:, panel p] * Lpp^-T
+static int predict_diag(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s) {
   const int np_ = m->Npad;
-  timer_begin("predict", s);
-  GPK_TRY(launch_se_build(dZ, M, Mpad, m->dX, m->N, np_, m->se, 0, 0, dR, np_, 0, s));
-  for (int p = 0; p < m->nP; ++p) {
-    const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
-    double* Lp = m->Lpanel(p);
-    for (int sb = 0; sb < w / 128; ++sb) {
-      const int cs = c0 + sb * 128, ro = cs - c0;
-      if (sb > 0) {
-        GemmNT g{};
-        g.A = dV + c0; g.lda = np_;
-        g.B = Lp + (long)ro * w; g.ldb = w;
-        g.C = dR + cs; g.ldc = np_;
-        g.m = Mpad; g.n = 128; g.k = ro; g.sub = 1;
-        GPK_TRY(launch_gemm_nt(g, false, s));
-      }
-      GemmNT g{};
-      g.A = dR + cs; g.lda = np_;
-      g.B = m->dDinv + (long)(cs / 128) * 128 * 128; g.ldb = 128;
-      g.C = dV + cs; g.ldc = np_;
-      g.m = Mpad; g.n = 128; g.k = 128; g.sub = 0;
-      GPK_TRY(launch_gemm_nt(g, false, s));
-    }
-    if (h - w > 0) {
+  const int c0 = m->pc0[p], w = m->pw[p];
+  double* Lp = m->Lpanel(p);
+  for (int sb = 0; sb < w / 128; ++sb) {
+    const int cs = c0 + sb * 128, ro = cs - c0;
+    if (sb > 0) {
       GemmNT g{};
       g.A = dV + c0; g.lda = np_;
-      g.B = Lp + (long)w * w; g.ldb = w;
-      g.C = dR + c0 + w; g.ldc = np_;
-      g.m = Mpad; g.n = h - w; g.k = w; g.sub = 1;
-      GPK_TRY(launch_gemm_auto(g, s));
+      g.B = Lp + (long)ro * w; g.ldb = w;
+      g.C = dR + cs; g.ldc = np_;
+      g.m = Mpad; g.n = 128; g.k = ro; g.sub = 1;
+      GPK_TRY(launch_gemm_nt(g, false, s));
     }
+    GemmNT g{};
+    g.A = dR + cs; g.lda = np_;
+    g.B = m->dDinv + (long)(cs / 128) * 128 * 128; g.ldb = 128;
+    g.C = dV + cs; g.ldc = np_;
+    g.m = Mpad; g.n = 128; g.k = 128; g.sub = 0;
+    GPK_TRY(launch_gemm_nt(g, false, s));
   }
-  GPK_TRY(launch_row_stats(dV, np_, M, np_, m->dw, m->se.sf2, dmean, dvar, s));
-  timer_end("predict", s);
+  return 0;
+}
+// R[:, cg0 : cg0+ncols] -= V[:, panel p] * Lp[(cg0-c0) : +ncols, :]^T
+static int predict_update(gpk_model* m, int p, int Mpad, int cg0, int ncols, double* dR, double* dV, hipStream_t s) {
+  if (ncols <= 0) return 0;
+  const int np_ = m->Npad;
+  const int c0 = m->pc0[p], w = m->pw[p];
+  GemmNT g{};
+  g.A = dV + c0; g.lda = np_;
+  g.B = m->Lpanel(p) + (long)(cg0 - c0) * w; g.ldb = w;
+  g.C = dR + cg0; g.ldc = np_;
+  g.m = Mpad; g.n = ncols; g.k = w; g.sub = 1;
+  // few 128x128 tiles (the look-ahead block column): 64x64 tiles put 4x as many CUs on the critical path
+  if ((long)(Mpad / 128) * (ncols / 128) < 96) return launch_gemm_nt(g, false, s);
+  return launch_gemm_auto(g, s);
+}
+
+int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, double* dV, double* dmean,
+                   double* dvar) {
+  hipStream_t sm = G.s_main, sp = G.s_panel;
+  const int np_ = m->Npad, nP = m->nP;
+  timer_begin("predict", sm);
+  GPK_TRY(launch_se_build(dZ, M, Mpad, m->dX, m->N, np_, m->se, 0, 0, dR, np_, 0, sm));
+  if (!G.lookahead || nP < 3) {
+    for (int p = 0; p < nP; ++p) {
+      GPK_TRY(predict_diag(m, p, Mpad, dR, dV, sm));
+      const int c1 = m->pc0[p] + m->pw[p];
+      GPK_TRY(predict_update(m, p, Mpad, c1, np_ - c1, dR, dV, sm));
+    }
+  } else {
+    // one panel of look-ahead, as in the factorisation: the latency-bound diagonal solves of panel p+1 run on
+    // s_panel while the wide update of panel p runs on s_main.
+    while ((int)G.ev_pool.size() < 2 * nP + 2) {
+      hipEvent_t e;
+      GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      G.ev_pool.push_back(e);
+    }
+    hipEvent_t* ev_diag = G.ev_pool.data();
+    hipEvent_t* ev_upd = G.ev_pool.data() + nP;
+    hipEvent_t ev_start = G.ev_pool[2 * nP];
+    GPK_HIP(hipEventRecord(ev_start, sm));
+    GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
+    GPK_TRY(predict_diag(m, 0, Mpad, dR, dV, sp));
+    GPK_HIP(hipEventRecord(ev_diag[0], sp));
+    for (int p = 0; p < nP; ++p) {
+      const int c1 = m->pc0[p] + m->pw[p];
+      const int wn = (p + 1 < nP) ? m->pw[p + 1] : 0;
+      if (p + 1 < nP) {
+        if (p > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_upd[p - 1], 0));
+        GPK_TRY(predict_update(m, p, Mpad, c1, wn, dR, dV, sp));
+        GPK_TRY(predict_diag(m, p + 1, Mpad, dR, dV, sp));
+        GPK_HIP(hipEventRecord(ev_diag[p + 1], sp));
+      }
+      GPK_HIP(hipStreamWaitEvent(sm, ev_diag[p], 0));
+      GPK_TRY(predict_update(m, p, Mpad, c1 + wn, np_ - c1 - wn, dR, dV, sm));
+      GPK_HIP(hipEventRecord(ev_upd[p], sm));
+    }
+    GPK_HIP(hipStreamWaitEvent(sm, ev_diag[nP - 1], 0));
+  }
+  GPK_TRY(launch_row_stats(dV, np_, M, np_, m->dw, m->se.sf2, dmean, dvar, sm));
+  timer_end("predict", sm);
   return 0;
 }
 
