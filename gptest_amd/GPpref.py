@@ -18,7 +18,7 @@ Reference quirks kept for parity: probit sigma stays at the const
 ``self.likelihood.set_sigma = ...`` (GPpref.py:115) assigns over the method; ``logdetK`` is
 ``sum(log(diag L))`` (GPpref.py:131) and ``log_marginal`` halves it again (GPpref.py:93); the Cholesky is
 retried with 10x jitter on ``LinAlgError`` (GPpref.py:126-135).  Parity for this module is UNPINNED (the
-reference cannot be imported: Python-2 + GPy); tests compare against ``oracle/gppref_oracle.py``.
+reference cannot be imported: Python-2 + GPy); the tests compare against a NumPy restatement of GPpref.py.
 """
 import ctypes
 

@@ -178,13 +178,33 @@ class GaussianProcess(object):
 
     def compute_prediction(self, testInput):
         """GPr.py:45-54 -> (fz (M,), cov_fz (M,)); latent variance, no +sn2 (GPr.py:51)."""
-        handle, _ = self._fitted(self.covFun.logHyp)
         Z = _as_points(testInput)
         X = _as_points(self.trainInput)
         if Z.shape[1] != X.shape[1]:
             raise ValueError("test inputs have dimension %d, training inputs %d" % (Z.shape[1], X.shape[1]))
         fz, fzp = _lib.out_array(Z.shape[0])
         cov, covp = _lib.out_array(Z.shape[0])
+        lh = np.ascontiguousarray(self.covFun.logHyp, dtype=np.float64)
+        if self._cache_key != lh.tobytes():
+            # nothing factored yet for these hyper-parameters: one fused call (K build, Cholesky and the
+            # prediction solve pipelined behind it), and the handle is kept for later calls
+            _lib.init()
+            if len(lh) != X.shape[1] + 2:
+                raise ValueError("log hyper-parameters must have d+2 = %d entries, got %d" % (X.shape[1] + 2, len(lh)))
+            yv = np.ascontiguousarray(np.asarray(self.trainTarget, dtype=np.float64).reshape(-1))
+            if len(yv) != X.shape[0]:
+                raise ValueError("targets have %d entries, inputs %d" % (len(yv), X.shape[0]))
+            h = ctypes.c_void_p()
+            nlml = ctypes.c_double()
+            rc = _lib.lib().gpk_fit_predict(X.ctypes.data_as(_lib.c_double_p), yv.ctypes.data_as(_lib.c_double_p),
+                                            X.shape[0], X.shape[1], lh.ctypes.data_as(_lib.c_double_p), 0.0,
+                                            Z.ctypes.data_as(_lib.c_double_p), Z.shape[0], ctypes.byref(h),
+                                            ctypes.byref(nlml), fzp, covp)
+            _lib.check(rc, "gpk_fit_predict")
+            self._cache = (_Handle(h), nlml.value)
+            self._cache_key = lh.tobytes()
+            return fz, cov
+        handle, _ = self._fitted(self.covFun.logHyp)
         rc = _lib.lib().gpk_predict(handle.ptr, Z.ctypes.data_as(_lib.c_double_p), Z.shape[0], fzp, covp)
         _lib.check(rc, "gpk_predict")
         return fz, cov

@@ -47,6 +47,7 @@ def _bind(l):
         "gpk_potrf": (i, [dp, i]),
         "gpk_fit": (i, [dp, dp, i, i, dp, d, i, c_void_pp, dp]),
         "gpk_predict": (i, [vp, dp, i, dp, dp]),
+        "gpk_fit_predict": (i, [dp, dp, i, i, dp, d, dp, i, c_void_pp, dp, dp, dp]),
         "gpk_solve": (i, [vp, dp, i, dp]),
         "gpk_solve_lower": (i, [vp, dp, i, dp]),
         "gpk_kmatvec": (i, [vp, dp, i, dp]),

@@ -49,17 +49,21 @@ int gpk_init(int device) {
     hipError_t e1 = hipExtStreamCreateWithCUMask(&G.s_main, words, m_all.data());
     hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&G.s_panel, words, m_all.data()) : e1;
     hipError_t e3 = e2 == hipSuccess ? hipExtStreamCreateWithCUMask(&G.s_leaf, words, m_leaf.data()) : e2;
+    if (e3 == hipSuccess) e3 = hipExtStreamCreateWithCUMask(&G.s_pred, words, m_all.data());
     masked = (e3 == hipSuccess);
     if (!masked) {
       (void)hipGetLastError();
       if (G.s_main) (void)hipStreamDestroy(G.s_main);
-      if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
+      if (G.s_pred) (void)hipStreamDestroy(G.s_pred);
+  G.s_pred = nullptr;
+  if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
   if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
   for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
   G.ev_ring.clear();
   for (hipEvent_t e : G.ev_pool) (void)hipEventDestroy(e);
   G.ev_pool.clear();
-      G.s_main = G.s_panel = G.s_leaf = nullptr;
+      if (G.s_pred) (void)hipStreamDestroy(G.s_pred);
+      G.s_main = G.s_panel = G.s_leaf = G.s_pred = nullptr;
     }
   }
   int lo = 0, hi = 0;
@@ -67,6 +71,7 @@ int gpk_init(int device) {
   if (!masked) {
     GPK_HIP(hipStreamCreateWithPriority(&G.s_main, hipStreamNonBlocking, lo));
     GPK_HIP(hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, hi));
+    GPK_HIP(hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, lo));
     G.s_leaf = G.s_panel;
   }
   G.cu_reserved = masked;
@@ -93,6 +98,8 @@ void gpk_shutdown(void) {
   for (hipEvent_t e : G.ev_free) (void)hipEventDestroy(e);
   G.ev_free.clear();
   if (G.s_main) (void)hipStreamDestroy(G.s_main);
+  if (G.s_pred) (void)hipStreamDestroy(G.s_pred);
+  G.s_pred = nullptr;
   if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
   if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
   for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
@@ -146,6 +153,8 @@ int gpk_set_option(const char* key, double value) {
     G.use_pp = (int)value;
   } else if (k == "pp_min_tiles") {
     G.pp_min_tiles = (int)value;
+  } else if (k == "fuse_predict") {
+    G.fuse_predict = (int)value;
   } else if (k == "timing") {
     G.timing = (int)value;
     if (!G.timing) timers_reset();
@@ -279,6 +288,57 @@ int gpk_fit(const double* X, const double* y, int N, int d, const double* log_hy
     if (!rc && hipMemcpyAsync(m->dy, y, (size_t)N * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
   }
   if (!rc) rc = fit_device(m);
+  if (rc) {
+    if (rc > 0) gpk_set_err(rc, "kernel matrix is not positive definite (leading minor %d)", rc);
+    model_destroy(m);
+    return rc;
+  }
+  if (nlml_out) *nlml_out = m->nlml;
+  *handle_out = m;
+  return 0;
+}
+
+int gpk_fit_predict(const double* X, const double* y, int N, int d, const double* log_hyp, double jitter,
+                    const double* Z, int M, gpk_model** handle_out, double* nlml_out, double* mean_out,
+                    double* var_out) {
+  if (!X || !y || !log_hyp || !Z || !handle_out || !mean_out || !var_out) return gpk_set_err(-1, "gpk_fit_predict: null pointer");
+  if (M < 1) return gpk_set_err(-1, "gpk_fit_predict: M=%d must be >= 1", M);
+  *handle_out = nullptr;
+  gpk_model* m = nullptr;
+  GPK_TRY(model_create(&m, N, d, false));
+  hipStream_t s = G.s_main;
+  const int Mpad = round_up(M, 128);
+  const size_t szR = (size_t)Mpad * m->Npad;
+  double *dZ = nullptr, *dR = nullptr, *dV = nullptr, *dmv = nullptr;
+  int rc = decode_hyp(log_hyp, d, jitter, m);
+  rc |= dev_alloc_t(&dZ, (size_t)M * d);
+  if (m->P == 1) {
+    rc |= dev_alloc_t(&dR, szR);
+    rc |= dev_alloc_t(&dV, szR);
+    rc |= dev_alloc_t(&dmv, (size_t)2 * Mpad);
+  }
+  m->has_y = true;
+  if (!rc && hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
+  if (!rc && hipMemsetAsync(m->dy, 0, (size_t)m->Npad * 8, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
+  if (!rc && hipMemcpyAsync(m->dy, y, (size_t)N * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
+  if (!rc && hipMemcpyAsync(dZ, Z, (size_t)M * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
+  if (!rc) {
+    if (m->P == 1) {
+      FusedPredict fp{dZ, M, Mpad, dR, dV, dmv, dmv + Mpad};
+      rc = fit_device(m, &fp);
+      if (!rc && (hipMemcpyAsync(mean_out, dmv, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                  hipMemcpyAsync(var_out, dmv + Mpad, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                  hipStreamSynchronize(s) != hipSuccess))
+        rc = gpk_set_err(-2, "fit_predict: result read-back failed");
+    } else {
+      rc = fit_device(m);
+      if (!rc) rc = predict_sharded(m, dZ, M, mean_out, var_out);
+    }
+  }
+  if (dZ) dev_free(dZ, (size_t)M * d * 8);
+  if (dR) dev_free(dR, szR * 8);
+  if (dV) dev_free(dV, szR * 8);
+  if (dmv) dev_free(dmv, (size_t)2 * Mpad * 8);
   if (rc) {
     if (rc > 0) gpk_set_err(rc, "kernel matrix is not positive definite (leading minor %d)", rc);
     model_destroy(m);
@@ -440,6 +500,14 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
   double* dZ = nullptr;
   int rc = decode_hyp(log_hyp, d, 0.0, m);
   rc |= dev_alloc_t(&dZ, (size_t)M * d);
+  const int Mpad1 = round_up(M, 128);
+  const size_t szR1 = (size_t)Mpad1 * m->Npad;
+  double *dR1 = nullptr, *dV1 = nullptr, *dmv1 = nullptr;
+  if (m->P == 1) {
+    rc |= dev_alloc_t(&dR1, szR1);
+    rc |= dev_alloc_t(&dV1, szR1);
+    rc |= dev_alloc_t(&dmv1, (size_t)2 * Mpad1);
+  }
   std::vector<double> hm(M), hv(M);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (!rc) {
@@ -461,10 +529,20 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
         } else if (it < warmup) {
           G.timing = 0;
         }
-        rc = fit_device(m);  // includes the 16-byte scalar read-back (the result of compute_likelihood)
-        if (rc) break;
-        rc = predict_sharded(m, dZ, M, hm.data(), hv.data());  // includes the result read-back
-        if (rc) break;
+        if (m->P == 1) {
+          // fused: the prediction solve is pipelined behind the factorisation (one K build, one Cholesky)
+          FusedPredict fp{dZ, M, Mpad1, dR1, dV1, dmv1, dmv1 + Mpad1};
+          rc = fit_device(m, &fp);  // includes the scalar read-back (the result of compute_likelihood)
+          if (rc) break;
+          if (hipMemcpyAsync(hm.data(), dmv1, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+              hipMemcpyAsync(hv.data(), dmv1 + Mpad1, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+              hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "bench: result read-back failed"); break; }
+        } else {
+          rc = fit_device(m);
+          if (rc) break;
+          rc = predict_sharded(m, dZ, M, hm.data(), hv.data());  // sharded over ranks, includes the read-back
+          if (rc) break;
+        }
       }
       G.timing = saved_timing;
       if (rc) break;
@@ -481,6 +559,9 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   if (dZ) dev_free(dZ, (size_t)M * d * 8);
+  if (dR1) dev_free(dR1, szR1 * 8);
+  if (dV1) dev_free(dV1, szR1 * 8);
+  if (dmv1) dev_free(dmv1, (size_t)2 * Mpad1 * 8);
   if (rc > 0) gpk_set_err(rc, "kernel matrix is not positive definite (leading minor %d)", rc);
   model_destroy(m);
   return rc;

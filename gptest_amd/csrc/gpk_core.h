@@ -18,6 +18,7 @@ struct Runtime {
   bool inited = false;
   int device = 0;
   hipStream_t s_main = nullptr, s_panel = nullptr, s_comm = nullptr;
+  hipStream_t s_pred = nullptr;   // prediction solve pipelined behind the factorisation (fused fit+predict)
   hipStream_t s_leaf = nullptr;   // CU-masked stream owning one reserved CU for the 1-workgroup leaf kernels
   bool cu_reserved = false;
   std::vector<hipEvent_t> ev_ring;
@@ -31,6 +32,7 @@ struct Runtime {
   int nb_big = 512, nb_big_until = 8192, nb_small = 128, nb_small_from = 2048, nb_auto = 1;
   int lookahead = 1;
   int timing = 0;
+  int fuse_predict = 1;  // bench / compute_prediction: overlap the prediction solve with the factorisation tail
   int xcd_sq = 1;              // XCD-aware 8x8-tile square order in the big GEMMs
   int use_persistent = 0;      // persistent XCD-aware 8-wave kernel for the rank-NB updates
   int persist_min_tiles = 1024; // below this many tiles the one-tile-per-workgroup kernel is used
@@ -83,8 +85,15 @@ struct gpk_model {
 int model_create(gpk_model** out, int N, int d, bool keep_k, int P = -1, int r = -1);
 void model_destroy(gpk_model* m);
 int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m);
-int fit_device(gpk_model* m);                                   // K build + potrf + w + scalars (inputs resident)
+// prediction job fused into a fit: V = Kzx L^-T is pipelined panel by panel behind the factorisation
+struct FusedPredict {
+  const double* dZ; int M, Mpad;
+  double *dR, *dV, *dmean, *dvar;
+};
+int fit_device(gpk_model* m, const FusedPredict* fp = nullptr);  // K build + potrf + w + scalars (inputs resident)
+extern int g_potrf_lookahead_used;  // 1 if the last potrf_device recorded per-panel events in G.ev_pool[0..nP)
 int potrf_device(gpk_model* m);                                 // dK -> dL, dDinv
+int ensure_ev_pool(int n);                                      // dependency events of the look-ahead schedules
 int build_K(gpk_model* m);                                      // dX -> dK (local block columns)
 int factor_panel(gpk_model* m, int p, hipStream_t s);          // owner only
 int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hipStream_t s);

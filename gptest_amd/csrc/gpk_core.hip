@@ -3,6 +3,7 @@
 #include <cmath>
 
 Runtime G;
+int g_potrf_lookahead_used = 0;
 extern "C" int gpk_comm_allreduce_max(double* inout, int n);
 static thread_local std::string g_err = "";
 
@@ -327,10 +328,13 @@ int dist_update(gpk_model* m, int p, int first_block, int nblocks_max, hipStream
   return launch_gemm_nt(g, true, s);
 }
 
-static hipEvent_t ev_new() {
-  hipEvent_t e;
-  (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-  return e;
+int ensure_ev_pool(int n) {
+  while ((int)G.ev_pool.size() < n) {
+    hipEvent_t e;
+    GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    G.ev_pool.push_back(e);
+  }
+  return 0;
 }
 
 // Right-looking with one panel of look-ahead: while the big SYRK of panel p runs on s_main, the
@@ -342,6 +346,7 @@ int potrf_device(gpk_model* m) {
   hipStream_t sm = G.s_main, sp = G.s_panel;
   GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
   const int nP = m->nP;
+  g_potrf_lookahead_used = 0;
   if (m->P > 1) return potrf_distributed(m);
   if (!G.lookahead || nP < 3) {
     for (int p = 0; p < nP; ++p) {
@@ -355,8 +360,8 @@ int potrf_device(gpk_model* m) {
     }
     return 0;
   }
-  if ((int)G.ev_pool.size() < 2 * nP + 2)
-    while ((int)G.ev_pool.size() < 2 * nP + 2) G.ev_pool.push_back(ev_new());
+  GPK_TRY(ensure_ev_pool(2 * nP + 4));
+  g_potrf_lookahead_used = 1;
   hipEvent_t* ev_panel = G.ev_pool.data();        // panel p factored (recorded on s_panel)
   hipEvent_t* ev_trail = G.ev_pool.data() + nP;   // rest-update of step p done (recorded on s_main)
   hipEvent_t ev_start = G.ev_pool[2 * nP];
@@ -420,11 +425,7 @@ static int potrf_distributed(gpk_model* m) {
     }
     return 0;
   }
-  while ((int)G.ev_pool.size() < 2 * nP + 2) {
-    hipEvent_t e;
-    GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    G.ev_pool.push_back(e);
-  }
+  GPK_TRY(ensure_ev_pool(2 * nP + 4));
   hipEvent_t* ev_panel = G.ev_pool.data();       // panel p available on this rank (recorded on s_panel)
   hipEvent_t* ev_trail = G.ev_pool.data() + nP;  // rest-update of step p done (recorded on s_main)
   hipEvent_t ev_start = G.ev_pool[2 * nP];
@@ -497,7 +498,10 @@ int trsv_backward(gpk_model* m, double* v) {
 }
 
 // ------------------------------------------------------------------ fused fit (inputs already in HBM)
-int fit_device(gpk_model* m) {
+static int predict_diag(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s);
+static int predict_update(gpk_model* m, int p, int Mpad, int cg0, int ncols, double* dR, double* dV, hipStream_t s);
+
+int fit_device(gpk_model* m, const FusedPredict* fp) {
   hipStream_t s = G.s_main;
   const int np_ = m->Npad;
   timer_begin("kbuild", s, (m->keep_k ? 8.0 : 4.0) * np_ * np_ + 8.0 * m->N * m->d);
@@ -506,8 +510,34 @@ int fit_device(gpk_model* m) {
   if (m->keep_k)
     GPK_HIP(hipMemcpyAsync(m->dKcopy, m->dK, (size_t)np_ * np_ * 8, hipMemcpyDeviceToDevice, s));
   timer_begin("potrf", s);
+  hipEvent_t ev_kb = nullptr;
+  const bool fuse = fp && G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3;
+  if (fuse) {  // Kzx only needs X: build it on the prediction stream while the factorisation starts
+    GPK_TRY(ensure_ev_pool(2 * m->nP + 4));
+    ev_kb = G.ev_pool[2 * m->nP + 2];
+    GPK_HIP(hipEventRecord(ev_kb, s));
+  }
   GPK_TRY(potrf_device(m));
   timer_end("potrf", s);
+  bool fused_done = false;
+  if (fuse && g_potrf_lookahead_used) {
+    // The forward substitution of panel p only needs panels <= p: queue it behind the per-panel events of the
+    // factorisation on its own stream.  While the trailing updates saturate the chip this merely re-orders
+    // work; in the latency-bound tail of the factorisation it fills the idle CUs.
+    hipStream_t sq = G.s_pred;
+    hipEvent_t* ev_panel = G.ev_pool.data();
+    GPK_HIP(hipStreamWaitEvent(sq, ev_kb, 0));
+    timer_begin("predict", sq);
+    GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq));
+    for (int p = 0; p < m->nP; ++p) {
+      GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
+      GPK_TRY(predict_diag(m, p, fp->Mpad, fp->dR, fp->dV, sq));
+      const int c1 = m->pc0[p] + m->pw[p];
+      GPK_TRY(predict_update(m, p, fp->Mpad, c1, np_ - c1, fp->dR, fp->dV, sq));
+    }
+    timer_end("predict", sq);
+    fused_done = true;
+  }
   GPK_TRY(launch_sum_log_diag(m->dDinv, m->N, m->dscal + 0, s));
   if (m->has_y) {
     timer_begin("solve_y", s);
@@ -515,6 +545,16 @@ int fit_device(gpk_model* m) {
     GPK_TRY(trsv_forward(m, m->dw));
     GPK_TRY(launch_dot(m->dw, m->dw, np_, m->dscal + 1, s));
     timer_end("solve_y", s);
+  }
+  if (fp) {
+    if (fused_done) {
+      hipEvent_t ev_pd = G.ev_pool[2 * m->nP + 3];
+      GPK_HIP(hipEventRecord(ev_pd, G.s_pred));
+      GPK_HIP(hipStreamWaitEvent(s, ev_pd, 0));
+      GPK_TRY(launch_row_stats(fp->dV, np_, fp->M, np_, m->dw, m->se.sf2, fp->dmean, fp->dvar, s));
+    } else {
+      GPK_TRY(predict_device(m, fp->dZ, fp->M, fp->Mpad, fp->dR, fp->dV, fp->dmean, fp->dvar));
+    }
   }
   double hs[2] = {0, 0};
   int hinfo = 0;
@@ -592,11 +632,7 @@ int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, 
   } else {
     // one panel of look-ahead, as in the factorisation: the latency-bound diagonal solves of panel p+1 run on
     // s_panel while the wide update of panel p runs on s_main.
-    while ((int)G.ev_pool.size() < 2 * nP + 2) {
-      hipEvent_t e;
-      GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      G.ev_pool.push_back(e);
-    }
+    GPK_TRY(ensure_ev_pool(2 * nP + 4));
     hipEvent_t* ev_diag = G.ev_pool.data();
     hipEvent_t* ev_upd = G.ev_pool.data() + nP;
     hipEvent_t ev_start = G.ev_pool[2 * nP];

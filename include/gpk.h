@@ -76,6 +76,11 @@ int gpk_fit(const double* X, const double* y, int N, int d, const double* log_hy
 /* GaussianProcess.compute_prediction: GPr.py:45-54.  mean = Kzx K^-1 y,
  * var = sf2 - diag(Kzx K^-1 Kxz)  (latent variance, no +sn2: GPr.py:51).      */
 int gpk_predict(gpk_model* h, const double* Z, int M, double* mean_out, double* var_out);
+/* compute_likelihood + compute_prediction in one call (GPr.py:45-69) sharing one K build and one Cholesky;
+ * the forward substitution of the prediction is pipelined panel by panel behind the factorisation. */
+int gpk_fit_predict(const double* X, const double* y, int N, int d, const double* log_hyp, double jitter,
+                    const double* Z, int M, gpk_model** handle_out, double* nlml_out, double* mean_out,
+                    double* var_out);
 /* K^-1 B for B (N, nrhs) row-major: replaces the explicit iK of GPr.py:63 / GPpref.py:129. */
 int gpk_solve(gpk_model* h, const double* B, int nrhs, double* X_out);
 /* L^-1 B (forward substitution only), B (N, nrhs) row-major. */
