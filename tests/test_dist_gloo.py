@@ -60,7 +60,7 @@ WORKER = textwrap.dedent(
     assert np.allclose(L, ref, rtol=1e-11, atol=1e-11), np.abs(L - ref).max()
     tdist.barrier()
     tdist.destroy_process_group()
-    sys.stdout.write("rank " + str(rank) + " ok\n")  # one write(): atomic on the shared pipe
+    sys.stdout.write("rank " + str(rank) + " ok" + chr(10))  # one write(): atomic on the shared pipe
     sys.stdout.flush()
     """
 )
@@ -98,7 +98,7 @@ def test_socket_bootstrap_two_processes(tmp_path):
         rank = int(os.environ["RANK"])
         got = dist.socket_bootstrap(bytes(range(128)) if rank == 0 else None)
         assert got == bytes(range(128))
-        sys.stdout.write("ok " + str(rank) + "\n")
+        sys.stdout.write("ok " + str(rank) + chr(10))
         """
     ) % ROOT
     procs = []
