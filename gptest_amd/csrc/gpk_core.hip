@@ -512,45 +512,63 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   timer_begin("potrf", s);
   hipEvent_t ev_kb = nullptr;
   const bool fuse = fp && G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3;
-  if (fuse) {  // Kzx only needs X: build it on the prediction stream while the factorisation starts
+  if (G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3 && (fuse || m->has_y)) {
+    // s_pred may start once K is built (Kzx only needs X, the y substitution only panels and y)
     GPK_TRY(ensure_ev_pool(2 * m->nP + 4));
     ev_kb = G.ev_pool[2 * m->nP + 2];
     GPK_HIP(hipEventRecord(ev_kb, s));
   }
   GPK_TRY(potrf_device(m));
   timer_end("potrf", s);
+  // Everything that only needs panels <= p is queued on s_pred behind the per-panel events of the
+  // factorisation: the forward substitution w = L^-1 y (two tiny kernels per panel) and, for a fused
+  // fit+predict, the forward substitution of the prediction.  While the trailing updates saturate the
+  // chip this merely re-orders work; in the latency-bound tail of the factorisation it fills idle CUs.
+  const bool pipelined = g_potrf_lookahead_used && G.s_pred && m->P == 1 && G.fuse_predict;
   bool fused_done = false;
-  if (fuse && g_potrf_lookahead_used) {
-    // The forward substitution of panel p only needs panels <= p: queue it behind the per-panel events of the
-    // factorisation on its own stream.  While the trailing updates saturate the chip this merely re-orders
-    // work; in the latency-bound tail of the factorisation it fills the idle CUs.
+  if (pipelined && (m->has_y || fuse)) {
     hipStream_t sq = G.s_pred;
     hipEvent_t* ev_panel = G.ev_pool.data();
+    if (!ev_kb) return gpk_set_err(-1, "internal: pipeline start event missing");
     GPK_HIP(hipStreamWaitEvent(sq, ev_kb, 0));
-    timer_begin("predict", sq);
-    GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq));
+    if (m->has_y) GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, sq));
+    if (fuse) {
+      timer_begin("predict", sq);
+      GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq));
+    }
     for (int p = 0; p < m->nP; ++p) {
       GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
-      GPK_TRY(predict_diag(m, p, fp->Mpad, fp->dR, fp->dV, sq));
-      const int c1 = m->pc0[p] + m->pw[p];
-      GPK_TRY(predict_update(m, p, fp->Mpad, c1, np_ - c1, fp->dR, fp->dV, sq));
+      const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
+      if (m->has_y) {
+        double* Lp = m->Lpanel(p);
+        GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, m->dw + c0, 0, sq));
+        GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, m->dw + c0, m->dw + c0 + w, sq));
+      }
+      if (fuse) {
+        GPK_TRY(predict_diag(m, p, fp->Mpad, fp->dR, fp->dV, sq));
+        GPK_TRY(predict_update(m, p, fp->Mpad, c0 + w, np_ - c0 - w, fp->dR, fp->dV, sq));
+      }
     }
-    timer_end("predict", sq);
-    fused_done = true;
+    if (fuse) {
+      timer_end("predict", sq);
+      fused_done = true;
+    }
+    hipEvent_t ev_pd = G.ev_pool[2 * m->nP + 3];
+    GPK_HIP(hipEventRecord(ev_pd, sq));
+    GPK_HIP(hipStreamWaitEvent(s, ev_pd, 0));
   }
   GPK_TRY(launch_sum_log_diag(m->dDinv, m->N, m->dscal + 0, s));
   if (m->has_y) {
     timer_begin("solve_y", s);
-    GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, s));
-    GPK_TRY(trsv_forward(m, m->dw));
+    if (!(pipelined && (m->has_y || fuse))) {
+      GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, s));
+      GPK_TRY(trsv_forward(m, m->dw));
+    }
     GPK_TRY(launch_dot(m->dw, m->dw, np_, m->dscal + 1, s));
     timer_end("solve_y", s);
   }
   if (fp) {
     if (fused_done) {
-      hipEvent_t ev_pd = G.ev_pool[2 * m->nP + 3];
-      GPK_HIP(hipEventRecord(ev_pd, G.s_pred));
-      GPK_HIP(hipStreamWaitEvent(s, ev_pd, 0));
       GPK_TRY(launch_row_stats(fp->dV, np_, fp->M, np_, m->dw, m->se.sf2, fp->dmean, fp->dvar, s));
     } else {
       GPK_TRY(predict_device(m, fp->dZ, fp->M, fp->Mpad, fp->dR, fp->dV, fp->dmean, fp->dvar));
