@@ -580,34 +580,12 @@ __global__ void pad_diag_local_kernel(double* K, long ldk, int N, int Npad, int 
 
 extern "C" {
 
-// Single-GPU emulation of the P-rank block-cyclic factorisation: P rank models live in this process,
-// the RCCL broadcast is replaced by device-to-device copies, everything else (ownership, local column
-// maps, the cyclic GEMM column map) is the production code.  L of rank `P-1` is returned.
-int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
-  GPK_TRY(rt_require());
-  if (!A || !L_out || N < 1 || P < 1 || P > 16) return gpk_set_err(-1, "gpk_test_dist_potrf: bad arguments");
+static int dist_emulate_factor(std::vector<gpk_model*>& ms, int N, double* L_out) {
+  const int P = (int)ms.size();
   hipStream_t s = G.s_main;
-  std::vector<gpk_model*> ms(P, nullptr);
+  const int nP = ms[0]->nP, np_ = ms[0]->Npad;
   int rc = 0;
-  for (int r = 0; r < P && !rc; ++r) rc = model_create(&ms[r], N, 1, false, P, r);
-  if (!rc) {
-    const int NB = ms[0]->NB, nP = ms[0]->nP, np_ = ms[0]->Npad;
-    for (int r = 0; r < P && !rc; ++r) {
-      gpk_model* m = ms[r];
-      if (hipMemsetAsync(m->dK, 0, (size_t)np_ * m->ldk * 8, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
-      if (hipMemsetAsync(m->dinfo, 0, 16, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
-      for (int lg = 0; lg < m->nloc && !rc; ++lg) {
-        const int g = (P > 1) ? lg * P + r : lg;
-        const int cg0 = g * NB;
-        int nc = N - cg0;
-        if (nc > NB) nc = NB;
-        if (nc <= 0) continue;
-        if (hipMemcpy2DAsync(m->dK + (size_t)lg * NB, (size_t)m->ldk * 8, A + cg0, (size_t)N * 8, (size_t)nc * 8, N,
-                             hipMemcpyHostToDevice, s) != hipSuccess)
-          rc = gpk_set_err(-2, "H2D failed");
-      }
-      if (!rc && np_ > N) hipLaunchKernelGGL(pad_diag_local_kernel, dim3(8), dim3(256), 0, s, m->dK, m->ldk, N, np_, NB, P, r);
-    }
+  {
     for (int p = 0; p < nP && !rc; ++p) {
       gpk_model* own = ms[p % P];
       rc = factor_panel(own, p, s);
@@ -636,11 +614,43 @@ int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
     if (!rc && worst > 0) rc = worst > N ? N : worst;
     if (!rc) rc = model_unpack_L(ms[P - 1], L_out);
   }
+  return rc;
+}
+
+// Single-GPU emulation of the P-rank block-cyclic factorisation: P rank models live in this process,
+// the RCCL broadcast is replaced by device-to-device copies, everything else (ownership, local column
+// maps, the cyclic GEMM column map) is the production code.  L of rank `P-1` is returned.
+int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
+  GPK_TRY(rt_require());
+  if (!A || !L_out || N < 1 || P < 1 || P > 16) return gpk_set_err(-1, "gpk_test_dist_potrf: bad arguments");
+  hipStream_t s = G.s_main;
+  std::vector<gpk_model*> ms(P, nullptr);
+  int rc = 0;
+  for (int r = 0; r < P && !rc; ++r) rc = model_create(&ms[r], N, 1, false, P, r);
+  if (!rc) {
+    const int NB = ms[0]->NB, np_ = ms[0]->Npad;
+    for (int r = 0; r < P && !rc; ++r) {
+      gpk_model* m = ms[r];
+      if (hipMemsetAsync(m->dK, 0, (size_t)np_ * m->ldk * 8, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
+      if (hipMemsetAsync(m->dinfo, 0, 16, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
+      for (int lg = 0; lg < m->nloc && !rc; ++lg) {
+        const int g = (P > 1) ? lg * P + r : lg;
+        const int cg0 = g * NB;
+        int nc = N - cg0;
+        if (nc > NB) nc = NB;
+        if (nc <= 0) continue;
+        if (hipMemcpy2DAsync(m->dK + (size_t)lg * NB, (size_t)m->ldk * 8, A + cg0, (size_t)N * 8, (size_t)nc * 8, N,
+                             hipMemcpyHostToDevice, s) != hipSuccess)
+          rc = gpk_set_err(-2, "H2D failed");
+      }
+      if (!rc && np_ > N) hipLaunchKernelGGL(pad_diag_local_kernel, dim3(8), dim3(256), 0, s, m->dK, m->ldk, N, np_, NB, P, r);
+    }
+    if (!rc) rc = dist_emulate_factor(ms, N, L_out);
+  }
   for (int r = 0; r < P; ++r)
     if (ms[r]) model_destroy(ms[r]);
   return rc;
 }
-
 
 int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile) {
   GPK_TRY(rt_require());
@@ -697,6 +707,28 @@ int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out) {
 }
 
 }  // extern "C"
+
+extern "C" int gpk_test_dist_fit(const double* X, int N, int d, const double* log_hyp, double jitter, int P, double* L_out) {
+  // as gpk_test_dist_potrf, but every virtual rank builds ITS block columns of K from X (build_K), which
+  // exercises the global-column bookkeeping of the kernel-matrix builder.
+  GPK_TRY(rt_require());
+  if (!X || !log_hyp || !L_out || N < 1 || P < 1 || P > 16) return gpk_set_err(-1, "gpk_test_dist_fit: bad arguments");
+  hipStream_t s = G.s_main;
+  std::vector<gpk_model*> ms(P, nullptr);
+  int rc = 0;
+  for (int r = 0; r < P && !rc; ++r) rc = model_create(&ms[r], N, d, false, P, r);
+  for (int r = 0; r < P && !rc; ++r) {
+    gpk_model* m = ms[r];
+    rc = decode_hyp(log_hyp, d, jitter, m);
+    if (!rc && hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
+    if (!rc && hipMemsetAsync(m->dinfo, 0, 16, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
+    if (!rc) rc = build_K(m);
+  }
+  if (!rc) rc = dist_emulate_factor(ms, N, L_out);
+  for (int r = 0; r < P; ++r)
+    if (ms[r]) model_destroy(ms[r]);
+  return rc;
+}
 
 // ---------------------------------------------------------------- micro-benchmarks
 typedef double d4_t __attribute__((ext_vector_type(4)));

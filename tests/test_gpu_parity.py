@@ -376,3 +376,25 @@ def test_regression_demo_flow_matches_reference_run(gpk):
     np.testing.assert_allclose(r["y_test"][:3], [1.87501298, 1.87062573, 1.86189206], atol=2e-4)
     np.testing.assert_allclose(r["cov_y"][:3], [0.01449844, 0.01055097, 0.00758511], atol=2e-5)
     assert np.all(np.isfinite(r["band"])) and 150 < r["funcalls"] < 600
+
+
+@pytest.mark.parametrize("N,d,P", [(1000, 3, 2), (1300, 8, 4), (2048, 4, 8)])
+def test_block_cyclic_fit_emulated_ranks(gpk, N, d, P):
+    """Every virtual rank builds ITS block columns of K(X,X) on the device (global-column bookkeeping of the
+    builder), then the emulated P-rank factorisation: L must equal the 1-GPU factor of the same K."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+
+    X, y, _, lh = orc.synthetic_problem(N, d, 4)
+    LP = np.empty((N, N))
+    lhc = np.ascontiguousarray(lh)
+    gpk.set_option("nb", 256)
+    rc = gpk.lib().gpk_test_dist_fit(_ptr(np.ascontiguousarray(X)), N, d, _ptr(lhc), 0.0, P, _ptr(LP))
+    assert rc == 0, gpk.last_error()
+    L1 = np.empty((N, N))
+    rc = gpk.lib().gpk_test_dist_fit(_ptr(np.ascontiguousarray(X)), N, d, _ptr(lhc), 0.0, 1, _ptr(L1))
+    assert rc == 0, gpk.last_error()
+    gpk.set_option("nb_auto", 1)
+    np.testing.assert_array_equal(LP, L1)
+    Lr = np.linalg.cholesky(orc.kxx(lh, X))
+    np.testing.assert_allclose(LP, Lr, rtol=1e-9, atol=1e-10)
