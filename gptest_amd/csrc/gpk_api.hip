@@ -43,11 +43,28 @@ int gpk_init(int device) {
     const int words = (ncu + 31) / 32;
     std::vector<uint32_t> m_all(words, 0u), m_leaf(words, 0u);
     for (int c = 0; c < ncu; ++c) m_all[c / 32] |= (1u << (c % 32));
-    const int r = ncu - 1;
-    m_all[r / 32] &= ~(1u << (r % 32));
-    m_leaf[r / 32] |= (1u << (r % 32));
+    // One reserved CU PER XCD: a queue whose mask names CUs of a single XCD is still dispatched round-robin over
+    // all 8 XCDs, and on the XCDs where its mask is empty the runtime lets it use every CU (measured with
+    // gpk_debug_cu_masks: a 1-bit mask ran on 57 different CUs), so a lone reserved CU only helps 1 launch in 8.
+    // Mask bit i <-> XCD (i % 8) when GPK_RESERVE_MODE=0 (default), XCD (i / (ncu/8)) when 1.
+    const char* env_mode = getenv("GPK_RESERVE_MODE");
+    const int mode = env_mode ? atoi(env_mode) : 0;
+    for (int x = 0; x < 8; ++x) {
+      const int r = (mode == 0) ? (ncu - 8 + x) : ((x + 1) * (ncu / 8) - 1);
+      m_all[r / 32] &= ~(1u << (r % 32));
+      m_leaf[r / 32] |= (1u << (r % 32));
+    }
     hipError_t e1 = hipExtStreamCreateWithCUMask(&G.s_main, words, m_all.data());
-    hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&G.s_panel, words, m_all.data()) : e1;
+    // s_panel (the latency-critical panel chain): high PRIORITY instead of a mask -- the two cannot be combined
+    // through HIP.  Its skinny GEMMs may also use the reserved CU; a leaf only ever follows them in stream
+    // order, so the CU is empty again when the leaf arrives.  GPK_PANEL_PRIO=0 restores the masked stream.
+    const char* env_pp = getenv("GPK_PANEL_PRIO");
+    const bool panel_prio = !(env_pp && env_pp[0] == '0');
+    int plo = 0, phi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+    hipError_t e2 = e1 != hipSuccess ? e1
+                    : panel_prio     ? hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, phi)
+                                     : hipExtStreamCreateWithCUMask(&G.s_panel, words, m_all.data());
     hipError_t e3 = e2 == hipSuccess ? hipExtStreamCreateWithCUMask(&G.s_leaf, words, m_leaf.data()) : e2;
     if (e3 == hipSuccess) e3 = hipExtStreamCreateWithCUMask(&G.s_pred, words, m_all.data());
     masked = (e3 == hipSuccess);
@@ -75,7 +92,7 @@ int gpk_init(int device) {
     G.s_leaf = G.s_panel;
   }
   G.cu_reserved = masked;
-  G.ncu = masked ? ncu - 1 : ncu;
+  G.ncu = masked ? ncu - 8 : ncu;
   GPK_HIP(hipStreamCreateWithPriority(&G.s_comm, hipStreamNonBlocking, hi));
   for (int i = 0; i < 64; ++i) {
     hipEvent_t e;
@@ -895,6 +912,94 @@ int gpk_bench_leaf(int dbg_skip, int reps, double* us_out) {
   dev_free(dD, 128 * 128 * 8);
   dev_free(dinfo, 16);
   return rc;
+}
+
+// which physical CU does a workgroup run on?  (XCC id, SE id, CU id from the hardware id registers)
+__global__ void whoami_kernel(unsigned* out, int spin) {
+  unsigned hw = 0, xcc = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = hw;
+    out[2 * blockIdx.x + 1] = xcc;
+  }
+}
+
+// returns in ids_main[0..nmain) / ids_leaf[0..nleaf) a packed (xcc<<16 | se<<8 | cu) per workgroup
+int gpk_debug_cu_masks(int nmain, unsigned* ids_main, int nleaf, unsigned* ids_leaf) {
+  GPK_TRY(rt_require());
+  unsigned *d1 = nullptr, *d2 = nullptr;
+  GPK_TRY(dev_alloc_t(&d1, (size_t)2 * nmain));
+  GPK_TRY(dev_alloc_t(&d2, (size_t)2 * nleaf));
+  hipLaunchKernelGGL(whoami_kernel, dim3(nmain), dim3(256), 0, G.s_main, d1, 200);
+  hipLaunchKernelGGL(whoami_kernel, dim3(nleaf), dim3(1024), 0, G.s_leaf ? G.s_leaf : G.s_main, d2, 50);
+  GPK_HIP(hipDeviceSynchronize());
+  std::vector<unsigned> h1(2 * nmain), h2(2 * nleaf);
+  GPK_HIP(hipMemcpy(h1.data(), d1, h1.size() * 4, hipMemcpyDeviceToHost));
+  GPK_HIP(hipMemcpy(h2.data(), d2, h2.size() * 4, hipMemcpyDeviceToHost));
+  auto pack = [](unsigned hw, unsigned xcc) {
+    const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 0x1, se = (hw >> 13) & 0x7;  // gfx9 HW_ID layout
+    return ((xcc & 0xf) << 16) | (se << 8) | (sh << 4) | cu;
+  };
+  for (int i = 0; i < nmain; ++i) ids_main[i] = pack(h1[2 * i], h1[2 * i + 1]);
+  for (int i = 0; i < nleaf; ++i) ids_leaf[i] = pack(h2[2 * i], h2[2 * i + 1]);
+  dev_free(d1, (size_t)2 * nmain * 4);
+  dev_free(d2, (size_t)2 * nleaf * 4);
+  return 0;
+}
+
+// leaf kernel on the reserved-CU stream while the GEMM stream keeps the rest of the chip busy
+int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended) {
+  const int dbg = reps >> 16;  // upper bits: leaf dbg_skip mode
+  reps &= 0xffff;
+  GPK_TRY(rt_require());
+  hipStream_t sl = G.s_leaf ? G.s_leaf : G.s_main, sm = G.s_main;
+  double *dA = nullptr, *dL = nullptr, *dD = nullptr, *gA = nullptr, *gC = nullptr;
+  int* dinfo = nullptr;
+  const int gm = 8192, gk = 256;
+  GPK_TRY(dev_alloc_t(&dA, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dL, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dD, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dinfo, 4));
+  GPK_TRY(dev_alloc_t(&gA, (size_t)gm * gk));
+  GPK_TRY(dev_alloc_t(&gC, (size_t)gm * gm));
+  std::vector<double> h(128 * 128);
+  for (int i = 0; i < 128; ++i)
+    for (int j = 0; j < 128; ++j) h[i * 128 + j] = (i == j ? 4.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
+  GPK_HIP(hipMemcpy(dA, h.data(), 128 * 128 * 8, hipMemcpyHostToDevice));
+  GPK_HIP(hipMemset(dinfo, 0, 16));
+  GPK_TRY(launch_fill(gA, (size_t)gm * gk, 1e-3, sm));
+  GPK_TRY(launch_fill(gC, (size_t)gm * gm, 1.0, sm));
+  GPK_HIP(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  auto run_leaves = [&](double* out) -> int {
+    GPK_HIP(hipEventRecord(e0, sl));
+    for (int r = 0; r < reps; ++r) GPK_TRY(launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg, sl));
+    GPK_HIP(hipEventRecord(e1, sl));
+    GPK_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *out = 1e3 * ms / reps;
+    int hi[8] = {0};
+    GPK_HIP(hipMemcpy(hi, dinfo, 32, hipMemcpyDeviceToHost));
+    if (dbg & 8) printf("   phases (us): load %.1f | eliminate+scale+L store %.1f | inverse %.1f | Dinv store issue %.1f\n", (hi[4]-hi[3])*0.01, (hi[5]-hi[4])*0.01, (hi[6]-hi[5])*0.01, (hi[7]-hi[6])*0.01);
+    if (dbg & 8) printf("   elimination: %d shader cycles, %d ticks of 10 ns -> %.3f GHz, %.1f us\n", hi[1], hi[2], hi[2] ? hi[1] / (hi[2] * 10.0) : 0.0, hi[2] * 0.01);
+    return 0;
+  };
+  GPK_TRY(run_leaves(us_alone));
+  GemmNT g{};
+  g.A = gA; g.lda = gk; g.B = gA; g.ldb = gk; g.C = gC; g.ldc = gm; g.m = gm; g.n = gm; g.k = gk; g.sub = 1; g.lower = 1;
+  for (int r = 0; r < 120; ++r) GPK_TRY(launch_gemm_nt(g, true, sm));  // ~15 ms of back-to-back trailing updates
+  GPK_TRY(run_leaves(us_contended));
+  GPK_HIP(hipDeviceSynchronize());
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dev_free(dA, 128 * 128 * 8); dev_free(dL, 128 * 128 * 8); dev_free(dD, 128 * 128 * 8); dev_free(dinfo, 16);
+  dev_free(gA, (size_t)gm * gk * 8); dev_free(gC, (size_t)gm * gm * 8);
+  return 0;
 }
 
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out) {

@@ -262,12 +262,17 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
   }
+  // Write-through (sc1) stores: the C tiles are not re-read before the next panel step, and lines left dirty in
+  // the XCD L2s make EVERY kernel boundary on the chip pay for their write-back (the end-of-kernel release of the
+  // latency-critical leaf on its reserved CU went from 60 us alone to 155-173 us beside this kernel).
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) (Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16)[c_off] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r)
+        __hip_atomic_store((Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16) + c_off, acc[i][j][r], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,11 +30,14 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   double* colbuf = S + 128 * PLD;       // [2][CBLD]; 128*129 and CBLD are even -> 16-byte aligned pair reads
   double* pivbuf = colbuf + 2 * CBLD;   // [128] pivots
   const int tid = threadIdx.x;
+#define LEAF_STAMP(k) do { if ((dbg_skip & 8) && tid == 0) info[k] = (int)__builtin_amdgcn_s_memrealtime(); } while (0)
+  LEAF_STAMP(3);
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int i = e >> 7, j = e & 127;
     S[i * PLD + j] = A[(long)i * lda + j];
   }
   __syncthreads();
+  LEAF_STAMP(4);
 
   const int i = tid & 127;
   const int kg = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform -> scalar branches below
@@ -45,6 +48,7 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
     a[q][1] = S[i * PLD + 16 * q + 2 * kg + 1];
   }
   int fail = 0;
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
   for (int jq = 0; jq < 8; ++jq) {
     if (dbg_skip & 1) break;
@@ -97,6 +101,10 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
     if (fail) break;
   }
   __syncthreads();
+  if ((dbg_skip & 8) && tid == 0) {  // diagnostic build path only: cycles / 100 MHz ticks of the elimination
+    info[1] = (int)(__builtin_amdgcn_s_memtime() - st_c0);
+    info[2] = (int)(__builtin_amdgcn_s_memrealtime() - st_r0);
+  }
   if (fail) {
     if (tid == 0) atomicCAS(info, 0, col0 + fail);
     // keep downstream kernels on finite data: emit identity factors for this tile
@@ -135,6 +143,7 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   __syncthreads();
   if (tid < 128) S[tid * PLD + tid] = 1.0 / S[tid * PLD + tid];
   __syncthreads();
+  LEAF_STAMP(5);
 
   // ---- in-place inverse, block sizes 1, 2, 4, 8: scalar
   const int nlev_scalar = (dbg_skip & 2) ? 0 : 4;
@@ -209,10 +218,12 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
     }
     __syncthreads();
   }
+  LEAF_STAMP(6);
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int ii = e >> 7, jj = e & 127;
     Dinv[e] = (jj <= ii) ? S[ii * PLD + jj] : 0.0;
   }
+  LEAF_STAMP(7);
 }
 
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0,

@@ -127,6 +127,10 @@ int gpk_test_dist_fit(const double* X, int N, int d, const double* log_hyp, doub
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out);
 /* leaf kernel timing; dbg_skip bit0 = skip elimination, bit1 = skip inverse (timing only). */
 int gpk_bench_leaf(int dbg_skip, int reps, double* us_out);
+/* diagnostic: physical placement (xcc<<16 | se<<8 | sh<<4 | cu) of workgroups launched on the GEMM / leaf streams. */
+int gpk_debug_cu_masks(int nmain, unsigned* ids_main, int nleaf, unsigned* ids_leaf);
+/* leaf on the reserved-CU stream, alone and while the GEMM stream saturates the other CUs. */
+int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended);
 /* pure v_mfma_f64_16x16x4_f64 issue loop on every CU: measured fp64 MFMA peak (TFLOP/s) of this device. */
 int gpk_bench_mfma_peak(int iters, double* tflops_out);
 int gpk_bench_mfma_mix(int mode, int waves_per_simd, int iters, double* tflops_out);
