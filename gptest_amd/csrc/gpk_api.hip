@@ -170,6 +170,8 @@ int gpk_set_option(const char* key, double value) {
     G.use_pp = (int)value;
   } else if (k == "pp_min_tiles") {
     G.pp_min_tiles = (int)value;
+  } else if (k == "leaf_direct_rows") {
+    G.leaf_direct_rows = (int)value;
   } else if (k == "fuse_predict") {
     G.fuse_predict = (int)value;
   } else if (k == "timing") {

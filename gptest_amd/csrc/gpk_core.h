@@ -32,6 +32,7 @@ struct Runtime {
   int nb_big = 512, nb_big_until = 8192, nb_small = 128, nb_small_from = 2048, nb_auto = 1;
   int lookahead = 1;
   int timing = 0;
+  int leaf_direct_rows = 3072;  // leaf goes on the chain stream (no reserved-CU hop) once this few rows remain
   int fuse_predict = 1;  // bench / compute_prediction: overlap the prediction solve with the factorisation tail
   int xcd_sq = 1;              // XCD-aware 8x8-tile square order in the big GEMMs
   int use_persistent = 0;      // persistent XCD-aware 8-wave kernel for the rank-NB updates

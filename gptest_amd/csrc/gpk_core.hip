@@ -242,8 +242,11 @@ static hipEvent_t ring_event() {
 }
 
 // The 1-workgroup leaf goes to the stream that owns the reserved CU; `s` is fenced around it.
-static int launch_leaf(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, hipStream_t s) {
-  hipStream_t sl = (G.cu_reserved && G.s_leaf) ? G.s_leaf : s;
+static int launch_leaf(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, hipStream_t s,
+                       int rows_left) {
+  // The reserved-CU stream costs two cross-stream hops (~13 us each).  Near the end of the factorisation the
+  // trailing updates no longer fill the chip, an empty CU is always at hand, and the leaf stays on the chain stream.
+  hipStream_t sl = (G.cu_reserved && G.s_leaf && rows_left > G.leaf_direct_rows) ? G.s_leaf : s;
   if (sl != s) {
     hipEvent_t e = ring_event();
     GPK_HIP(hipEventRecord(e, s));
@@ -278,7 +281,7 @@ int factor_panel(gpk_model* m, int p, hipStream_t s) {
       GPK_TRY(launch_gemm_nt(g, false, s));
     }
     double* Dt = m->dDinv + (long)(cs / 128) * 128 * 128;
-    GPK_TRY(launch_leaf(Acol, ldk, Lp + (long)ro * w + sb * 128, w, Dt, m->dinfo, cs, s));
+    GPK_TRY(launch_leaf(Acol, ldk, Lp + (long)ro * w + sb * 128, w, Dt, m->dinfo, cs, s, h - ro));
     if (h - ro - 128 > 0) {
       // L[cs+128:, sub-panel] = A[cs+128:, cs:cs+128] * Dinv^T
       GemmNT g{};
@@ -360,7 +363,7 @@ int potrf_device(gpk_model* m) {
     }
     return 0;
   }
-  GPK_TRY(ensure_ev_pool(2 * nP + 4));
+  GPK_TRY(ensure_ev_pool(2 * nP + 6));
   g_potrf_lookahead_used = 1;
   hipEvent_t* ev_panel = G.ev_pool.data();        // panel p factored (recorded on s_panel)
   hipEvent_t* ev_trail = G.ev_pool.data() + nP;   // rest-update of step p done (recorded on s_main)
@@ -425,7 +428,7 @@ static int potrf_distributed(gpk_model* m) {
     }
     return 0;
   }
-  GPK_TRY(ensure_ev_pool(2 * nP + 4));
+  GPK_TRY(ensure_ev_pool(2 * nP + 6));
   hipEvent_t* ev_panel = G.ev_pool.data();       // panel p available on this rank (recorded on s_panel)
   hipEvent_t* ev_trail = G.ev_pool.data() + nP;  // rest-update of step p done (recorded on s_main)
   hipEvent_t ev_start = G.ev_pool[2 * nP];
@@ -514,7 +517,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   const bool fuse = fp && G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3;
   if (G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3 && (fuse || m->has_y)) {
     // s_pred may start once K is built (Kzx only needs X, the y substitution only panels and y)
-    GPK_TRY(ensure_ev_pool(2 * m->nP + 4));
+    GPK_TRY(ensure_ev_pool(2 * m->nP + 6));
     ev_kb = G.ev_pool[2 * m->nP + 2];
     GPK_HIP(hipEventRecord(ev_kb, s));
   }
@@ -530,21 +533,24 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     hipStream_t sq = G.s_pred;
     hipEvent_t* ev_panel = G.ev_pool.data();
     if (!ev_kb) return gpk_set_err(-1, "internal: pipeline start event missing");
+    hipStream_t sy = G.s_comm ? G.s_comm : sq;  // the y substitution gets its own stream (idle on a single GPU)
     GPK_HIP(hipStreamWaitEvent(sq, ev_kb, 0));
-    if (m->has_y) GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, sq));
+    if (sy != sq) GPK_HIP(hipStreamWaitEvent(sy, ev_kb, 0));
+    if (m->has_y) GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, sy));
     if (fuse) {
       timer_begin("predict", sq);
       GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq));
     }
     for (int p = 0; p < m->nP; ++p) {
-      GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
       const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
       if (m->has_y) {
         double* Lp = m->Lpanel(p);
-        GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, m->dw + c0, 0, sq));
-        GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, m->dw + c0, m->dw + c0 + w, sq));
+        GPK_HIP(hipStreamWaitEvent(sy, ev_panel[p], 0));
+        GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, m->dw + c0, 0, sy));
+        GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, m->dw + c0, m->dw + c0 + w, sy));
       }
       if (fuse) {
+        GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
         GPK_TRY(predict_diag(m, p, fp->Mpad, fp->dR, fp->dV, sq));
         GPK_TRY(predict_update(m, p, fp->Mpad, c0 + w, np_ - c0 - w, fp->dR, fp->dV, sq));
       }
@@ -556,6 +562,11 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     hipEvent_t ev_pd = G.ev_pool[2 * m->nP + 3];
     GPK_HIP(hipEventRecord(ev_pd, sq));
     GPK_HIP(hipStreamWaitEvent(s, ev_pd, 0));
+    if (sy != sq) {
+      hipEvent_t ev_yd = G.ev_pool[2 * m->nP + 4];
+      GPK_HIP(hipEventRecord(ev_yd, sy));
+      GPK_HIP(hipStreamWaitEvent(s, ev_yd, 0));
+    }
   }
   GPK_TRY(launch_sum_log_diag(m->dDinv, m->N, m->dscal + 0, s));
   if (m->has_y) {
@@ -650,7 +661,7 @@ int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, 
   } else {
     // one panel of look-ahead, as in the factorisation: the latency-bound diagonal solves of panel p+1 run on
     // s_panel while the wide update of panel p runs on s_main.
-    GPK_TRY(ensure_ev_pool(2 * nP + 4));
+    GPK_TRY(ensure_ev_pool(2 * nP + 6));
     hipEvent_t* ev_diag = G.ev_pool.data();
     hipEvent_t* ev_upd = G.ev_pool.data() + nP;
     hipEvent_t ev_start = G.ev_pool[2 * nP];
