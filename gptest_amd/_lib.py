@@ -66,7 +66,6 @@ def _bind(l):
         "gpk_bench_gemm_nt": (i, [i, i, i, i, i, i, dp]),
         "gpk_bench_mfma_peak": (i, [i, dp]),
         "gpk_bench_mfma_peak2": (i, [i, i, i, dp]),
-        "gpk_bench_mfma_mix": (i, [i, i, i, dp]),
         "gpk_bench_leaf": (i, [i, i, dp]),
         "gpk_bench_leaf_contended": (i, [i, dp, dp]),
         "gpk_debug_cu_masks": (i, [i, ctypes.POINTER(ctypes.c_uint), i, ctypes.POINTER(ctypes.c_uint)]),

@@ -66,7 +66,14 @@ int gpk_init(int device) {
                     : panel_prio     ? hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, phi)
                                      : hipExtStreamCreateWithCUMask(&G.s_panel, words, m_all.data());
     hipError_t e3 = e2 == hipSuccess ? hipExtStreamCreateWithCUMask(&G.s_leaf, words, m_leaf.data()) : e2;
-    if (e3 == hipSuccess) e3 = hipExtStreamCreateWithCUMask(&G.s_pred, words, m_all.data());
+    if (e3 == hipSuccess) {
+      // s_pred (forward substitutions pipelined behind the panels): priority instead of a mask, otherwise its
+      // kernels queue behind thousands of trailing-update workgroups and the whole backlog (2.7 ms measured)
+      // is left over when the factorisation ends.  GPK_PRED_PRIO=0 restores the masked stream.
+      const char* env_qp = getenv("GPK_PRED_PRIO");
+      if (env_qp && env_qp[0] == '0') e3 = hipExtStreamCreateWithCUMask(&G.s_pred, words, m_all.data());
+      else e3 = hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, phi);
+    }
     masked = (e3 == hipSuccess);
     if (!masked) {
       (void)hipGetLastError();
@@ -162,14 +169,6 @@ int gpk_set_option(const char* key, double value) {
     g_gemm_variant = (int)value;
   } else if (k == "xcd_sq") {
     G.xcd_sq = (int)value;
-  } else if (k == "use_persistent") {
-    G.use_persistent = (int)value;
-  } else if (k == "persist_min_tiles") {
-    G.persist_min_tiles = (int)value;
-  } else if (k == "use_pp") {
-    G.use_pp = (int)value;
-  } else if (k == "pp_min_tiles") {
-    G.pp_min_tiles = (int)value;
   } else if (k == "leaf_direct_rows") {
     G.leaf_direct_rows = (int)value;
   } else if (k == "fuse_predict") {
@@ -686,7 +685,7 @@ int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, 
     GemmNT g{};
     g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
     g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
-    rc = (tile == 1) ? launch_gemm_nt_pp(g, G.ncu, s) : (tile == 9) ? launch_gemm_nt8p(g, s) : launch_gemm_nt(g, tile == 128, s);
+    rc = launch_gemm_nt(g, tile == 128, s);
     if (rc) break;
     if (hipMemcpyAsync(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
     if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "test_gemm: %s", hipGetErrorString(hipGetLastError())); break; }
@@ -775,70 +774,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters, 
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-// issue-pacing experiments: what between two f64 MFMAs lets the matrix pipe run closer to 64 cycles/MFMA?
-template <int MODE>
-__global__ __launch_bounds__(256) void mfma_mix_kernel(double* out, int iters, double seed) {
-  __shared__ double sh[1024];
-  d4_t acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = (d4_t){0, 0, 0, 0};
-  sh[threadIdx.x] = seed + threadIdx.x;
-  sh[threadIdx.x + 256] = seed - threadIdx.x;
-  __syncthreads();
-  double a[8], b[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { a[i] = seed + threadIdx.x * 1e-3 * (i + 1); b[i] = seed - threadIdx.x * 1e-3 * (i + 1); }
-  const double* p = sh + (threadIdx.x & 63);
-  double dummy = 0;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (MODE == 1) { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i], acc[i], 0, 0, 0); }
-      else if (MODE == 2) { double t = p[(i * 64 + (it & 1) * 512) & 1023]; acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[i], 0, 0, 0); dummy += t; }
-      else if (MODE == 3) { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[i], 0, 0, 0); asm volatile("s_nop 7\n\ts_nop 7"); }
-            else if (MODE == 5) { double t0 = p[(i * 64) & 1023]; double t1 = p[(i * 64 + 32) & 1023]; acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, t1, acc[i], 0, 0, 0); }
-      else { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[i], 0, 0, 0); }
-    }
-  }
-  double s = dummy;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
 extern "C" {
-
-int gpk_bench_mfma_mix(int mode, int waves_per_simd, int iters, double* tflops_out) {
-  GPK_TRY(rt_require());
-  hipStream_t s = G.s_main;
-  const int blocks = 256 * waves_per_simd;
-  double* d = nullptr;
-  GPK_TRY(dev_alloc_t(&d, (size_t)blocks * 256));
-  hipEvent_t e0, e1;
-  GPK_HIP(hipEventCreate(&e0));
-  GPK_HIP(hipEventCreate(&e1));
-  auto go = [&](int n) {
-    switch (mode) {
-      case 1: hipLaunchKernelGGL(mfma_mix_kernel<1>, dim3(blocks), dim3(256), 0, s, d, n, 0.5); break;
-      case 2: hipLaunchKernelGGL(mfma_mix_kernel<2>, dim3(blocks), dim3(256), 0, s, d, n, 0.5); break;
-      case 3: hipLaunchKernelGGL(mfma_mix_kernel<3>, dim3(blocks), dim3(256), 0, s, d, n, 0.5); break;
-      case 5: hipLaunchKernelGGL(mfma_mix_kernel<5>, dim3(blocks), dim3(256), 0, s, d, n, 0.5); break;
-      default: hipLaunchKernelGGL(mfma_mix_kernel<0>, dim3(blocks), dim3(256), 0, s, d, n, 0.5); break;
-    }
-  };
-  go(iters / 10 + 1);
-  GPK_HIP(hipEventRecord(e0, s));
-  go(iters);
-  GPK_HIP(hipEventRecord(e1, s));
-  GPK_HIP(hipEventSynchronize(e1));
-  float ms = 0;
-  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
-  if (tflops_out) *tflops_out = (double)blocks * 4 * (double)iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  dev_free(d, (size_t)blocks * 256 * 8);
-  return 0;
-}
 
 // nacc in {1,2,4,8,16,32} independent accumulators per wave; waves_per_simd in {1,2,3,4}
 int gpk_bench_mfma_peak2(int nacc, int waves_per_simd, int iters, double* tflops_out) {
@@ -1020,12 +956,12 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
   GPK_TRY(launch_fill(dC, (size_t)m * n, 1.0, s));
   GemmNT g{};
   g.A = dA; g.lda = k; g.B = lower ? dA : dB; g.ldb = k; g.C = dC; g.ldc = n;
-  g.m = m; g.n = n; g.k = k; g.sub = 1; g.lower = lower & 1; g.dbg = lower >> 1;
+  g.m = m; g.n = n; g.k = k; g.sub = 1; g.lower = lower & 1;
   extern int g_gemm_variant;
   const int saved_variant = g_gemm_variant;
   if (tile == 4) g_gemm_variant = 4;
   if (tile == 8) g_gemm_variant = 8;
-  auto go = [&]() { return (tile == 1) ? launch_gemm_nt_pp(g, G.ncu, s) : (tile == 9) ? launch_gemm_nt8p(g, s) : launch_gemm_nt(g, tile != 64, s); };
+  auto go = [&]() { return launch_gemm_nt(g, tile != 64, s); };
   int rc = go();
   hipEvent_t e0, e1;
   GPK_HIP(hipEventCreate(&e0));

@@ -35,10 +35,6 @@ struct Runtime {
   int leaf_direct_rows = 3072;  // leaf goes on the chain stream (no reserved-CU hop) once this few rows remain
   int fuse_predict = 1;  // bench / compute_prediction: overlap the prediction solve with the factorisation tail
   int xcd_sq = 1;              // XCD-aware 8x8-tile square order in the big GEMMs
-  int use_persistent = 0;      // persistent XCD-aware 8-wave kernel for the rank-NB updates
-  int persist_min_tiles = 1024; // below this many tiles the one-tile-per-workgroup kernel is used
-  int use_pp = 0;        // experimental persistent pipelined GEMM (k_gemm_pp.hip); slower than the 8-wave kernel, off
-  int pp_min_tiles = 384; // below this many 128x128 tiles the plain kernel (2 workgroups/CU) is used
   int ncu = 256;         // CUs available to the GEMM streams
   int small_tile_rows = 4096;  // GEMMs with n == 128 use the 64x64 tile below this many rows... (see potrf)
   // comm

@@ -24,20 +24,10 @@ int rt_require() {
 }
 
 int launch_gemm_auto(const GemmNT& g, hipStream_t s) {
-  if (G.use_persistent && g.sub && g.cyc_P == 0 && g.m % 128 == 0 && g.n % 128 == 0 && (!g.lower || g.m == g.n)) {
-    const long ntm = g.m / 128, ntn = g.n / 128;
-    const long nt = g.lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
-    if (nt >= G.persist_min_tiles) return launch_gemm_nt8p(g, s);
-  }
   if (G.xcd_sq && g.cyc_P == 0 && g.m % 128 == 0 && g.n % 128 == 0 && (long)(g.m / 128) * (g.n / 128) >= 8192) {
     GemmNT h = g;
     h.xcd_sq = 1;
     return launch_gemm_nt(h, true, s);
-  }
-  if (G.use_pp && g.sub && g.cyc_P == 0 && (g.k == 256 || g.k == 512) && g.m % 128 == 0 && g.n % 128 == 0) {
-    const long ntm = g.m / 128, ntn = g.n / 128;
-    const long nt = g.lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
-    if (nt >= G.pp_min_tiles) return launch_gemm_nt_pp(g, G.ncu, s);
   }
   return launch_gemm_nt(g, true, s);
 }

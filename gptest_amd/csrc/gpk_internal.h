@@ -43,15 +43,10 @@ struct GemmNT {
   long row_g0;   // global row index of C row 0
   long brow_g0;  // global row index of B row 0 (B tile row = gcol(tj) - brow_g0 when cyc_P > 0 or lower)
   int xcd_sq;    // 8-wave kernel: XCD-aware 8x8-tile square order (single GPU)
-  int dbg;       // timing experiments only (pipelined kernel): 1 no C traffic, 2 no A/B loads, 4 no barrier, 8 no LDS writes
 };
 // tile128 = true: 128x128 block tile (4x4 MFMA tiles per wave); false: 64x64 (2x2 per wave).
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s);
-// persistent 8-wave kernel with XCD-aware 8x8-tile squares (C -= A*B^T, single GPU)
-int launch_gemm_nt8p(const GemmNT& g, hipStream_t s);
-// persistent software-pipelined variant for C -= A*B^T with k in {256, 512} (k_gemm_pp.hip)
-int launch_gemm_nt_pp(const GemmNT& g, int ncu, hipStream_t s);
-// picks the pipelined kernel when the shape allows and there are enough tiles to pipeline
+// the 8-wave kernel, with the XCD-aware tile order for the largest updates
 int launch_gemm_auto(const GemmNT& g, hipStream_t s);
 
 // ---------------------------------------------------------------- leaf factor

@@ -275,150 +275,6 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Persistent form of the 8-wave kernel for C -= A*B^T (single GPU): 2 workgroups per CU walk the tile
-// list, so there is no workgroup launch/drain gap between tiles, the stores of tile t are fire-and-
-// forget, and the first K-slab of tile t+1 is fetched during the last slab of tile t.
-// Tile order: the grid is cut into 8x8-tile squares, one square per XCD at a time (blocks b and b+8
-// share an XCD: speed only, never correctness), so the 64 tiles an XCD works on share 8 A and 8 B
-// row-blocks = 4 MiB = its L2, instead of streaming a different B block per tile from the MALL.
-struct TileXY { int ti, tj, ok; };
-
-__device__ __forceinline__ TileXY sq_tile(const GemmNT& g, int xcd, int slot, int sq_idx, int ntm, int ntn) {
-  // squares are enumerated row-major over the (SM x SN) square grid (lower: only squares with J <= I)
-  TileXY t;
-  t.ok = 0;
-  t.ti = t.tj = 0;
-  const int SM = (ntm + 7) >> 3, SN = (ntn + 7) >> 3;
-  int I, J;
-  if (g.lower) {
-    const int nsq = SM * (SM + 1) / 2;
-    if (sq_idx >= nsq) { t.ok = -1; return t; }
-    int r = (int)((sqrtf(8.0f * (float)sq_idx + 1.0f) - 1.0f) * 0.5f);
-    while (r * (r + 1) / 2 > sq_idx) --r;
-    while ((r + 1) * (r + 2) / 2 <= sq_idx) ++r;
-    I = r;
-    J = sq_idx - r * (r + 1) / 2;
-  } else {
-    if (sq_idx >= SM * SN) { t.ok = -1; return t; }
-    I = sq_idx / SN;
-    J = sq_idx - I * SN;
-  }
-  const int ti = I * 8 + (slot >> 3), tj = J * 8 + (slot & 7);
-  if (ti >= ntm || tj >= ntn) return t;
-  if (g.lower && tj > ti) return t;
-  t.ti = ti; t.tj = tj; t.ok = 1;
-  (void)xcd;
-  return t;
-}
-
-__global__ __launch_bounds__(512, 4) void gemm_nt8p_kernel(GemmNT g) {
-  constexpr int BT = 128;
-  __shared__ double lds[2 * 2 * BT * LDS_LD];
-  double* As = lds;
-  double* Bs = lds + 2 * BT * LDS_LD;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 2, wn = wid & 3;
-  const int lrow = tid >> 3, lchk = (tid & 7) * 2;
-  const int fr = lane & 15, fg = lane >> 4;
-  const unsigned c_off = (unsigned)fg * (unsigned)g.ldc + (unsigned)fr;
-  const unsigned a_off = (unsigned)lrow * (unsigned)g.lda + (unsigned)lchk;
-  const unsigned b_off = (unsigned)lrow * (unsigned)g.ldb + (unsigned)lchk;
-  const int ntm = g.m / BT, ntn = g.n / BT;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;  // 64 slots per XCD (grid = 512)
-  const int nk = g.k / BK;
-
-  d2 ra[2], rb[2];
-  auto gload = [&](const double* Ag, const double* Bg, int kt) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      ra[p] = *reinterpret_cast<const d2*>(Ag + (long)(p * 64) * g.lda + kt * BK + a_off);
-      rb[p] = *reinterpret_cast<const d2*>(Bg + (long)(p * 64) * g.ldb + kt * BK + b_off);
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      d2 na = {-ra[p].x, -ra[p].y};
-      *reinterpret_cast<d2*>(As + (buf * BT + p * 64 + lrow) * LDS_LD + lchk) = na;
-      *reinterpret_cast<d2*>(Bs + (buf * BT + p * 64 + lrow) * LDS_LD + lchk) = rb[p];
-    }
-  };
-
-  // first tile of this workgroup
-  int sq = xcd;
-  TileXY cur = sq_tile(g, xcd, slot, sq, ntm, ntn);
-  while (cur.ok == 0) { sq += 8; cur = sq_tile(g, xcd, slot, sq, ntm, ntn); }
-  if (cur.ok < 0) return;
-  const double* Ag = g.A + (long)cur.ti * BT * g.lda;
-  const double* Bg = g.B + (long)cur.tj * BT * g.ldb;
-  gload(Ag, Bg, 0);
-
-  while (true) {
-    double* Cw = g.C + ((long)cur.ti * BT + wm * 64) * g.ldc + (long)cur.tj * BT + wn * 32;
-    d4 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = (Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16)[c_off];
-    // next tile (its first slab is fetched during this tile's last slab)
-    int nsq = sq + 8;
-    TileXY nxt = sq_tile(g, xcd, slot, nsq, ntm, ntn);
-    while (nxt.ok == 0) { nsq += 8; nxt = sq_tile(g, xcd, slot, nsq, ntm, ntn); }
-    const double* Agn = g.A + (long)nxt.ti * BT * g.lda;
-    const double* Bgn = g.B + (long)nxt.tj * BT * g.ldb;
-
-    lstore(0);  // slab 0 of this tile (already in registers)
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) gload(Ag, Bg, kt + 1);
-      else if (nxt.ok > 0) gload(Agn, Bgn, 0);
-      const double* Ab = As + (buf * BT + wm * 64 + fr) * LDS_LD + fg;
-      const double* Bb = Bs + (buf * BT + wn * 32 + fr) * LDS_LD + fg;
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 4) {
-        double a[4], b[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = Ab[i * 16 * LDS_LD + kk];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = Bb[j * 16 * LDS_LD + kk];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-      if (kt + 1 < nk) lstore(buf ^ 1);
-      __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) (Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16)[c_off] = acc[i][j][r];
-    if (nxt.ok < 0) break;
-    cur = nxt;
-    sq = nsq;
-    Ag = Agn;
-    Bg = Bgn;
-  }
-}
-
-int launch_gemm_nt8p(const GemmNT& g, hipStream_t s) {
-  if (g.m <= 0 || g.n <= 0) return 0;
-  if (!g.sub || g.cyc_P != 0 || g.m % 128 || g.n % 128 || g.k % BK || (g.lower && g.m != g.n))
-    return gpk_set_err(-1, "gemm_nt8p: unsupported shape/mode m=%d n=%d k=%d", g.m, g.n, g.k);
-  if ((g.lda & 1) || (g.ldb & 1) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15))
-    return gpk_set_err(-1, "gemm_nt8p: operands must be 16-byte aligned with even leading dimensions");
-  hipLaunchKernelGGL(gemm_nt8p_kernel, dim3(512), dim3(512), 0, s, g);
-  GPK_HIP(hipGetLastError());
-  return 0;
-}
-
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
   const int BT = tile128 ? 128 : 64;
   if (g.m <= 0 || g.n <= 0) return 0;

@@ -133,7 +133,6 @@ int gpk_debug_cu_masks(int nmain, unsigned* ids_main, int nleaf, unsigned* ids_l
 int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended);
 /* pure v_mfma_f64_16x16x4_f64 issue loop on every CU: measured fp64 MFMA peak (TFLOP/s) of this device. */
 int gpk_bench_mfma_peak(int iters, double* tflops_out);
-int gpk_bench_mfma_mix(int mode, int waves_per_simd, int iters, double* tflops_out);
 int gpk_bench_mfma_peak2(int nacc, int waves_per_simd, int iters, double* tflops_out);
 /* factor one 128x128 SPD tile: L_out (128x128 lower) and Dinv_out = inv(L). Returns info. */
 int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out);

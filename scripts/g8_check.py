@@ -21,7 +21,7 @@ ms = ctypes.c_double()
 t = (ctypes.c_double * 2)()
 l.gpk_bench_mfma_peak2(8, 4, 40000, t); print("calibration: pure MFMA 4 waves/SIMD %.2f TFLOP/s at %.3f GHz" % (t[0], t[1]))
 for (m, n, k, lower) in [(16128, 16128, 256, 1), (15872, 15872, 512, 1), (8192, 8192, 256, 1), (4096, 4096, 256, 1), (2048, 2048, 256, 1), (1024, 16128, 256, 0), (1024, 15872, 512, 0), (1024, 8192, 256, 0)]:
-    for tile, nm in ((8, "8-wave"), (10, "8-wave xcd-squares")):
+    for tile, nm in ((4, "4-wave (64x64 wave tiles)"), (8, "8-wave"), (10, "8-wave xcd-squares")):
         rc = l.gpk_bench_gemm_nt(m, n, k, lower, tile, 3, ctypes.byref(ms))
         fl = (m * n * k) if lower else 2.0 * m * n * k
         print("gemm m=%5d n=%5d k=%4d lower=%d %-18s: %.3f ms %.2f TFLOP/s" % (m, n, k, lower, nm, ms.value, fl / ms.value / 1e9))
