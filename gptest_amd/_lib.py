@@ -63,6 +63,7 @@ def _bind(l):
         "gpk_test_potf2_128": (i, [dp, dp, dp]),
         "gpk_test_dist_potrf": (i, [dp, i, i, dp]),
         "gpk_test_dist_fit": (i, [dp, i, i, dp, d, i, dp]),
+        "gpk_bench_se_build": (i, [i, i, i, i, i, dp]),
         "gpk_bench_gemm_nt": (i, [i, i, i, i, i, i, dp]),
         "gpk_bench_mfma_peak": (i, [i, dp]),
         "gpk_bench_mfma_peak2": (i, [i, i, i, dp]),

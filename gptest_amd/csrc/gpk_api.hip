@@ -940,6 +940,39 @@ int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended) {
   return 0;
 }
 
+// device-resident timing of the kernel-matrix builder: mode 0 SE, 1 squared distance, 2 stores only
+int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_out) {
+  GPK_TRY(rt_require());
+  hipStream_t s = G.s_main;
+  const int np_ = round_up(N, 128);
+  double *dX = nullptr, *dK = nullptr;
+  GPK_TRY(dev_alloc_t(&dX, (size_t)N * d));
+  GPK_TRY(dev_alloc_t(&dK, (size_t)np_ * np_));
+  std::vector<double> h((size_t)N * d);
+  unsigned long long st = 88172645463325252ull;
+  for (auto& v : h) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = (double)(st >> 11) / 9007199254740992.0; }
+  GPK_HIP(hipMemcpyAsync(dX, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
+  SEParams se{};
+  se.d = d; se.sf2 = 1.0; se.diag_add = 0.01;
+  for (int k = 0; k < d; ++k) se.ell[k] = 0.7;
+  int rc = launch_se_build(dX, N, np_, dX, N, np_, se, 1, mode, dK, np_, lower, s);
+  hipEvent_t e0, e1;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  GPK_HIP(hipEventRecord(e0, s));
+  for (int r = 0; r < reps && !rc; ++r) rc = launch_se_build(dX, N, np_, dX, N, np_, se, 1, mode, dK, np_, lower, s);
+  GPK_HIP(hipEventRecord(e1, s));
+  GPK_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (ms_out) *ms_out = ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dev_free(dX, (size_t)N * d * 8);
+  dev_free(dK, (size_t)np_ * np_ * 8);
+  return rc;
+}
+
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out) {
   GPK_TRY(rt_require());
   hipStream_t s = G.s_main;

@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
     if (mode == 1) {
       v0 = s0;
       v1 = s1;
+    } else if (mode == 2) {  // timing experiment: stores only
+      v0 = 1.0;
+      v1 = 2.0;
     } else {
       v0 = p.sf2 * exp(-0.5 * s0);
       v1 = p.sf2 * exp(-0.5 * s1);

@@ -123,6 +123,8 @@ int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, 
 int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out);
 /* same emulation, every virtual rank builds its own block columns of K(X,X) on the device first. */
 int gpk_test_dist_fit(const double* X, int N, int d, const double* log_hyp, double jitter, int P, double* L_out);
+/* device-resident timing of the kernel-matrix builder (mode 0 SE, 1 squared distance, 2 stores only). */
+int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_out);
 /* device-resident timing of the MFMA GEMM: C (m x n) -= A (m x k) B (n x k)^T, `reps` launches; ms per launch. */
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out);
 /* leaf kernel timing; dbg_skip bit0 = skip elimination, bit1 = skip inverse (timing only). */
