@@ -398,3 +398,67 @@ def test_block_cyclic_fit_emulated_ranks(gpk, N, d, P):
     np.testing.assert_array_equal(LP, L1)
     Lr = np.linalg.cholesky(orc.kxx(lh, X))
     np.testing.assert_allclose(LP, Lr, rtol=1e-9, atol=1e-10)
+
+
+# ----------------------------------------------------------------------------- more edge cases
+def test_generic_dimension_path(gpk):
+    """d > 8 takes the generic (LDS column points) builder: parity vs the verbatim oracle."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+
+    X, y, Z, lh = orc.synthetic_problem(500, 11, 37)
+    gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", X, y)
+    nl = gp.compute_likelihood(lh)[0, 0]
+    fz, cov = gp.compute_prediction(Z)
+    nl_o, fz_o, cov_o = orc.posterior_verbatim(lh, X, y, Z)
+    assert abs(nl - nl_o) <= RTOL * abs(nl_o)
+    np.testing.assert_allclose(fz, fz_o, rtol=RTOL, atol=RTOL * np.abs(fz_o).max())
+    np.testing.assert_allclose(cov, cov_o, rtol=0, atol=RTOL)
+    np.testing.assert_allclose(gp.covFun.compute_Kxx_matrix(), orc.kxx(lh, X), rtol=1e-12, atol=1e-14)
+
+
+def test_fused_and_separate_calls_agree(gpk):
+    """compute_prediction on a cold cache = one fused gpk_fit_predict (prediction pipelined behind the
+    factorisation on its own stream); after compute_likelihood it is gpk_predict on the cached factor.
+    Same kernels, same per-element summation order: the results must agree to the last bit."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+
+    X, y, Z, lh = orc.synthetic_problem(3000, 5, 300)
+    a = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", X, y)
+    fa, ca = a.compute_prediction(Z)                      # fused
+    b = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", X, y)
+    nl = b.compute_likelihood(lh)                          # fit only
+    fb, cb = b.compute_prediction(Z)                      # predict on the cached handle
+    np.testing.assert_array_equal(fa, fb)
+    np.testing.assert_array_equal(ca, cb)
+    assert a.compute_likelihood(lh)[0, 0] == nl[0, 0]
+    gpk.set_option("fuse_predict", 0)
+    try:
+        c = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", X, y)
+        fc, cc = c.compute_prediction(Z)
+    finally:
+        gpk.set_option("fuse_predict", 1)
+    np.testing.assert_array_equal(fa, fc)
+    np.testing.assert_array_equal(ca, cc)
+
+
+def test_c4_size_on_one_gpu(gpk):
+    """N = 32768, d = 8 (the size of BASELINE config 4) on one GPU: 8 GiB of K, 4 GiB of L.  Properties:
+    the fit succeeds, y - mean(X_train) = sn2 * K^-1 y on a sample, variances in [0, sf2]."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+
+    N, d = 32768, 8
+    X, y, _, lh = orc.synthetic_problem(N, d, 8)
+    h, nlml = GPr.fit_handle(X, y, lh)
+    assert np.isfinite(nlml)
+    alpha = np.empty((N, 1))
+    assert gpk.lib().gpk_solve(h.ptr, _ptr(np.ascontiguousarray(y.reshape(N, 1))), 1, _ptr(alpha)) == 0
+    sub = np.ascontiguousarray(X[-256:])
+    mean = np.empty(256)
+    var = np.empty(256)
+    assert gpk.lib().gpk_predict(h.ptr, _ptr(sub), 256, _ptr(mean), _ptr(var)) == 0
+    sn2, sf2 = np.exp(lh[-1]) ** 2, np.exp(lh[-2]) ** 2
+    np.testing.assert_allclose(y[-256:] - mean, sn2 * alpha[-256:, 0], rtol=0, atol=1e-8)
+    assert np.all(var > -1e-9) and np.all(var <= sf2 + 1e-12)
