@@ -187,6 +187,8 @@ double gpk_get_option(const char* key) {
   if (k == "lookahead") return G.lookahead;
   if (k == "timing") return G.timing;
   if (k == "pool_bytes") return (double)G.pool_bytes;
+  if (k == "potrf_enqueue_ms") return G.last_potrf_enqueue_ms;
+  if (k == "pipe_enqueue_ms") return G.last_pipe_enqueue_ms;
   if (k == "cu_reserved") return G.cu_reserved ? 1.0 : 0.0;
   return NAN;
 }

@@ -31,6 +31,7 @@ struct Runtime {
   // chain hides behind the update, nb in the middle, nb_small at the tail where the chain IS the critical path
   int nb_big = 512, nb_big_until = 8192, nb_small = 128, nb_small_from = 2048, nb_auto = 1;
   int lookahead = 1;
+  double last_potrf_enqueue_ms = 0.0, last_pipe_enqueue_ms = 0.0;  // host time spent queueing the last factorisation
   int timing = 0;
   int leaf_direct_rows = 3072;  // leaf goes on the chain stream (no reserved-CU hop) once this few rows remain
   int fuse_predict = 1;  // bench / compute_prediction: overlap the prediction solve with the factorisation tail

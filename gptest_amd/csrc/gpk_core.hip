@@ -1,6 +1,7 @@
 // Runtime + blocked Cholesky driver + fused fit/predict (host side of libgpk.so).
 #include "gpk_core.h"
 #include <cmath>
+#include <chrono>
 
 Runtime G;
 int g_potrf_lookahead_used = 0;
@@ -511,12 +512,15 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     ev_kb = G.ev_pool[2 * m->nP + 2];
     GPK_HIP(hipEventRecord(ev_kb, s));
   }
+  const auto host_t0 = std::chrono::steady_clock::now();
   GPK_TRY(potrf_device(m));
+  G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   timer_end("potrf", s);
   // Everything that only needs panels <= p is queued on s_pred behind the per-panel events of the
   // factorisation: the forward substitution w = L^-1 y (two tiny kernels per panel) and, for a fused
   // fit+predict, the forward substitution of the prediction.  While the trailing updates saturate the
   // chip this merely re-orders work; in the latency-bound tail of the factorisation it fills idle CUs.
+  const auto host_t1 = std::chrono::steady_clock::now();
   const bool pipelined = g_potrf_lookahead_used && G.s_pred && m->P == 1 && G.fuse_predict;
   bool fused_done = false;
   if (pipelined && (m->has_y || fuse)) {
@@ -558,6 +562,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
       GPK_HIP(hipStreamWaitEvent(s, ev_yd, 0));
     }
   }
+  G.last_pipe_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count();
   GPK_TRY(launch_sum_log_diag(m->dDinv, m->N, m->dscal + 0, s));
   if (m->has_y) {
     timer_begin("solve_y", s);
