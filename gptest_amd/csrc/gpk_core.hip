@@ -402,6 +402,15 @@ static int bcast_panel(gpk_model* m, int p, hipStream_t s) {
   GPK_TRY(comm_bcast(m->dDinv + (size_t)(c0 / 128) * 128 * 128, (size_t)(w / 128) * 128 * 128, p % m->P, s));
   return 0;
 }
+static double dist_update_flops(const gpk_model* m, int p, int first_block, int nblocks_max) {
+  double f = 0.0;
+  int cnt = 0;
+  for (int lg = first_block; lg < m->nloc && cnt < nblocks_max; ++lg, ++cnt) {
+    const long g = (long)lg * m->P + m->r;
+    f += (double)(m->Npad - g * m->NB) * m->NB * m->pw[p];
+  }
+  return f;
+}
 static inline int first_local_block_after(const gpk_model* m, int p) {  // # local blocks with global index <= p
   return (p >= m->r) ? (p - m->r) / m->P + 1 : 0;
 }
@@ -413,7 +422,7 @@ static int potrf_distributed(gpk_model* m) {
     for (int p = 0; p < nP; ++p) {
       if (p % P == r) GPK_TRY(factor_panel(m, p, sm));
       GPK_TRY(bcast_panel(m, p, sm));
-      timer_begin("trailing", sm);
+      timer_begin("trailing", sm, dist_update_flops(m, p, first_local_block_after(m, p), 1 << 30));
       GPK_TRY(dist_update(m, p, first_local_block_after(m, p), 1 << 30, sm));
       timer_end("trailing", sm);
     }
@@ -441,7 +450,7 @@ static int potrf_distributed(gpk_model* m) {
       GPK_HIP(hipEventRecord(ev_panel[p + 1], sp));
     }
     GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
-    timer_begin("trailing", sm);
+    timer_begin("trailing", sm, dist_update_flops(m, p, lg0 + (own_next ? 1 : 0), 1 << 30));
     GPK_TRY(dist_update(m, p, lg0 + (own_next ? 1 : 0), 1 << 30, sm));
     timer_end("trailing", sm);
     GPK_HIP(hipEventRecord(ev_trail[p], sm));
