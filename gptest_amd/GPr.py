@@ -215,3 +215,14 @@ class GaussianProcess(object):
             raise AttributeError("compute_likelihood needs covFunName='SE' and meanFunName='zero'")
         _, nlml = self._fitted(hyp)
         return np.array([[nlml]])
+
+    def compute_likelihood_gradient(self, hyp):
+        """Extension (not in the reference, whose demos hand-set ``hyp``): ``(nlml (1,1), grad (d+2,))`` with
+        ``grad = d nlml / d hyp`` in the log parametrisation of GPr.py:93-97, from the factor
+        ``compute_likelihood(hyp)`` already holds in HBM.  Suits ``scipy.optimize.minimize(..., jac=True)``."""
+        if self.meanFun == [] or self.covFunName != "SE":
+            raise AttributeError("compute_likelihood_gradient needs covFunName='SE' and meanFunName='zero'")
+        handle, nlml = self._fitted(hyp)
+        grad, gp = _lib.out_array(len(np.asarray(hyp).reshape(-1)))
+        _lib.check(_lib.lib().gpk_nlml_grad(handle.ptr, gp), "gpk_nlml_grad")
+        return np.array([[nlml]]), grad

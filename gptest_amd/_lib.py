@@ -52,6 +52,7 @@ def _bind(l):
         "gpk_solve_lower": (i, [vp, dp, i, dp]),
         "gpk_kmatvec": (i, [vp, dp, i, dp]),
         "gpk_kgather": (i, [vp, ctypes.POINTER(ctypes.c_longlong), i, dp]),
+        "gpk_nlml_grad": (i, [vp, dp]),
         "gpk_model_scalar": (i, [vp, i, dp]),
         "gpk_model_get_L": (i, [vp, dp]),
         "gpk_free": (i, [vp]),

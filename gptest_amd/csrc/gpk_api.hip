@@ -460,6 +460,15 @@ int gpk_kgather(gpk_model* m, const long long* idx, int nidx, double* out) {
   return rc;
 }
 
+int gpk_nlml_grad(gpk_model* m, double* grad_out) {
+  GPK_TRY(rt_require());
+  if (!m || !grad_out) return gpk_set_err(-1, "gpk_nlml_grad: null pointer");
+  timers_reset();
+  int rc = nlml_grad_device(m, grad_out);
+  if (!rc) rc = timers_resolve();
+  return rc;
+}
+
 int gpk_model_scalar(gpk_model* m, int which, double* out) {
   if (!m || !out) return gpk_set_err(-1, "gpk_model_scalar: null pointer");
   switch (which) {

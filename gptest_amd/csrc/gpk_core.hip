@@ -693,6 +693,78 @@ int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, 
   return 0;
 }
 
+// ------------------------------------------------------------------ gradient of the nlml (SURVEY 8f "next": hyper-parameter fit)
+// d nlml / d theta = 1/2 tr((Kinv - alpha alpha^T) dK/dtheta),  theta = log_hyp (GPr.py:93-97 parametrisation).
+// Kinv comes from the factor already in HBM with two sweeps of the NT GEMM, both at the N^3/3 flop count of the
+// factorisation because they only touch the non-zero (upper) part of V = L^-T:
+//   1. V = I L^-T   : the row substitution of predict_device applied to the identity; after panel p only rows
+//                     < c0+w of V[:, panel p] are non-zero, so every GEMM runs on the first c0+w rows only.
+//   2. -Kinv = -V V^T (lower): one rank-w update per panel on the leading (c0+w)^2 block.
+// The d+2 traces are then one fused pass over the lower triangle that recomputes the SE kernel on the fly.
+int nlml_grad_device(gpk_model* m, double* h_grad) {
+  if (m->P > 1) return gpk_set_err(-1, "gpk_nlml_grad: not available on a block-cyclic (multi-GPU) model");
+  if (!m->has_y) return gpk_set_err(-1, "gpk_nlml_grad: model was fitted without targets");
+  hipStream_t s = G.s_main;
+  const int np_ = m->Npad, nP = m->nP, N = m->N, d = m->d;
+  const size_t sq = (size_t)np_ * np_;
+  const int nt = (N + 127) / 128;
+  double *dR = nullptr, *dV = nullptr, *dNK = nullptr, *dalpha = nullptr, *dpart = nullptr, *dout = nullptr;
+  int rc = 0;
+  rc |= dev_alloc_t(&dR, sq);
+  rc |= dev_alloc_t(&dV, sq);
+  rc |= dev_alloc_t(&dNK, sq);
+  rc |= dev_alloc_t(&dalpha, (size_t)np_);
+  rc |= dev_alloc_t(&dpart, (size_t)nt * nt * (d + 2));
+  rc |= dev_alloc_t(&dout, (size_t)(d + 2));
+  auto cleanup = [&]() {
+    if (dR) dev_free(dR, sq * 8);
+    if (dV) dev_free(dV, sq * 8);
+    if (dNK) dev_free(dNK, sq * 8);
+    if (dalpha) dev_free(dalpha, (size_t)np_ * 8);
+    if (dpart) dev_free(dpart, (size_t)nt * nt * (d + 2) * 8);
+    if (dout) dev_free(dout, (size_t)(d + 2) * 8);
+  };
+  if (rc) { cleanup(); return rc; }
+  auto body = [&]() -> int {
+    timer_begin("grad_inv", s, 2.0 * (double)np_ * np_ * np_ / 3.0);
+    GPK_HIP(hipMemsetAsync(dR, 0, sq * 8, s));
+    GPK_HIP(hipMemsetAsync(dV, 0, sq * 8, s));
+    GPK_HIP(hipMemsetAsync(dNK, 0, sq * 8, s));
+    GPK_TRY(launch_set_diag(dR, np_, np_, 1.0, s));
+    for (int p = 0; p < nP; ++p) {
+      const int c1 = m->pc0[p] + m->pw[p];
+      GPK_TRY(predict_diag(m, p, c1, dR, dV, s));
+      GPK_TRY(predict_update(m, p, c1, c1, np_ - c1, dR, dV, s));
+    }
+    for (int p = 0; p < nP; ++p) {
+      const int c0 = m->pc0[p], w = m->pw[p];
+      GemmNT g{};
+      g.A = dV + c0; g.lda = np_;
+      g.B = dV + c0; g.ldb = np_;
+      g.C = dNK; g.ldc = np_;
+      g.m = c0 + w; g.n = c0 + w; g.k = w; g.sub = 1; g.lower = 1;
+      GPK_TRY(launch_gemm_auto(g, s));
+    }
+    timer_end("grad_inv", s);
+    timer_begin("grad_terms", s);
+    GPK_HIP(hipMemcpyAsync(dalpha, m->dw, (size_t)np_ * 8, hipMemcpyDeviceToDevice, s));
+    GPK_TRY(trsv_backward(m, dalpha));
+    GPK_TRY(launch_nlml_grad_terms(m->dX, N, d, dNK, np_, dalpha, m->se, dpart, dout, s));
+    timer_end("grad_terms", s);
+    std::vector<double> t(d + 2);
+    GPK_HIP(hipMemcpyAsync(t.data(), dout, (size_t)(d + 2) * 8, hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < d; ++k) h_grad[k] = 0.5 * t[k];
+    h_grad[d] = t[d];
+    h_grad[d + 1] = m->sn2 * t[d + 1];
+    return 0;
+  };
+  rc = body();
+  if (rc) (void)hipStreamSynchronize(s);
+  cleanup();
+  return rc;
+}
+
 // ------------------------------------------------------------------ prediction entry shared by gpk_predict / bench
 int predict_sharded(gpk_model* m, const double* dZ, int M, double* h_mean, double* h_var) {
   hipStream_t s = G.s_main;

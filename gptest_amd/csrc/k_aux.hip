@@ -345,3 +345,114 @@ int launch_gather2d(const double* K, long ldk, const long long* idx, int nidx, d
   GPK_HIP(hipGetLastError());
   return 0;
 }
+
+__global__ void set_diag_kernel(double* p, long ld, int n, double v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[(long)i * ld + i] = v;
+}
+int launch_set_diag(double* p, long ld, int n, double v, hipStream_t s) {
+  hipLaunchKernelGGL(set_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, ld, n, v);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- nlml gradient reductions
+// grad terms over the lower triangle of  A = Kinv - alpha alpha^T  (NK holds -Kinv):
+//   out[0..d)  : sum_ij A_ij Kf_ij (x_ik - x_jk)^2 / l_k^2      (-> 2 * d nlml / d log l_k)
+//   out[d]     : sum_ij A_ij Kf_ij                                (-> d nlml / d log sigma_f)
+//   out[d+1]   : trace(A)                                         (-> d nlml / d log sigma_n / sn2)
+// Kf_ij = sf2 exp(-r2/2) is recomputed on the fly (no second N^2 read).  One workgroup per 128x128 lower tile
+// writes d+2 partial sums (fixed tree), a second kernel adds the tile partials in a fixed order.
+template <int D>
+__global__ __launch_bounds__(256) void nlml_grad_tiles_kernel(const double* __restrict__ X, int N,
+                                                              const double* __restrict__ NK, long ldk,
+                                                              const double* __restrict__ alpha, SEParams p,
+                                                              double* __restrict__ partial) {
+  __shared__ double rs[128 * D];
+  __shared__ double cs[128 * D];
+  __shared__ double sm[16];
+  const int tc = blockIdx.x, tr = blockIdx.y;
+  const int ntile = gridDim.x;
+  double* outp = partial + ((long)tr * ntile + tc) * (D + 2);
+  const int tid = threadIdx.x;
+  if (tc > tr) {
+    if (tid < D + 2) outp[tid] = 0.0;
+    return;
+  }
+  const int r0 = tr * 128, c0 = tc * 128;
+  for (int e = tid; e < 128 * D; e += 256) {
+    const int i = e / D, k = e - i * D;
+    rs[e] = (r0 + i < N) ? X[(long)(r0 + i) * D + k] / p.ell[k] : 0.0;
+    cs[k * 128 + i] = (c0 + i < N) ? X[(long)(c0 + i) * D + k] / p.ell[k] : 0.0;  // [k][j]: lanes hit distinct banks
+  }
+  __syncthreads();
+  double acc[D + 2];
+#pragma unroll
+  for (int k = 0; k < D + 2; ++k) acc[k] = 0.0;
+  const int lane = tid & 63, w = tid >> 6;
+  for (int rr = 0; rr < 32; ++rr) {
+    const int i = w * 32 + rr, gi = r0 + i;
+    if (gi >= N) continue;
+    const double ai = alpha[gi];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = lane + 64 * h, gj = c0 + j;
+      if (gj >= N || gj > gi) continue;
+      double dk[D];
+      double r2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double e = rs[i * D + k] - cs[k * 128 + j];
+        dk[k] = e * e;
+        r2 += dk[k];
+      }
+      const double kf = p.sf2 * exp(-0.5 * r2);
+      const double a = -NK[(long)gi * ldk + gj] - ai * alpha[gj];
+      const double wgt = (gi == gj) ? 1.0 : 2.0;  // symmetric: the strict lower part counts twice
+      const double akf = wgt * a * kf;
+#pragma unroll
+      for (int k = 0; k < D; ++k) acc[k] += akf * dk[k];
+      acc[D] += akf;
+      if (gi == gj) acc[D + 1] += a;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < D + 2; ++k) {
+    double v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    if (tid == 0) outp[k] = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+  }
+}
+__global__ void nlml_grad_final_kernel(const double* __restrict__ partial, long ntiles, int nterm, double* out) {
+  __shared__ double sm[16];
+  const int k = blockIdx.x;
+  double v = 0.0;
+  for (long t = threadIdx.x; t < ntiles; t += blockDim.x) v += partial[t * nterm + k];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = 0.0;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) r += sm[wv];
+    out[k] = r;
+  }
+}
+int launch_nlml_grad_terms(const double* X, int N, int d, const double* NK, long ldk, const double* alpha, const SEParams& p,
+                           double* partial, double* out, hipStream_t s) {
+  const int nt = (N + 127) / 128;
+  dim3 grid(nt, nt), block(256);
+#define GPK_GRAD_CASE(DD) \
+  case DD: hipLaunchKernelGGL(nlml_grad_tiles_kernel<DD>, grid, block, 0, s, X, N, NK, ldk, alpha, p, partial); break;
+  switch (d) {
+    GPK_GRAD_CASE(1) GPK_GRAD_CASE(2) GPK_GRAD_CASE(3) GPK_GRAD_CASE(4)
+    GPK_GRAD_CASE(5) GPK_GRAD_CASE(6) GPK_GRAD_CASE(7) GPK_GRAD_CASE(8)
+    default: return gpk_set_err(-1, "nlml gradient: input dimension d=%d outside 1..8", d);
+  }
+#undef GPK_GRAD_CASE
+  hipLaunchKernelGGL(nlml_grad_final_kernel, dim3(d + 2), dim3(1024), 0, s, partial, (long)nt * nt, d + 2, out);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}

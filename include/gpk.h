@@ -89,6 +89,10 @@ int gpk_solve_lower(gpk_model* h, const double* B, int nrhs, double* X_out);
 int gpk_kmatvec(gpk_model* h, const double* B, int nrhs, double* out);
 /* out[p*nidx+q] = K[idx[p], idx[q]] from the kept copy (GPpref Newton step, GPpref.py:142-143). */
 int gpk_kgather(gpk_model* h, const long long* idx, int nidx, double* out);
+/* Gradient of the nlml of GPr.py:57-69 with respect to the d+2 log hyper-parameters (same order as log_hyp:
+ * d length scales, signal sd, noise sd), re-using the factor of the fit.  The reference has no gradient (its
+ * demos hand-set hyp); this is the "next" row of SURVEY 8(f) for fitting hyper-parameters.  Single-GPU models. */
+int gpk_nlml_grad(gpk_model* h, double* grad_out);
 /* scalars of the last fit: which = 0 nlml, 1 sum log L_ii, 2 y^T K^-1 y, 3 sf2, 4 sn2. */
 int gpk_model_scalar(gpk_model* h, int which, double* out);
 /* copy L out as dense lower-triangular (N,N) row-major. */

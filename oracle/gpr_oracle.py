@@ -133,6 +133,30 @@ def posterior_efficient(log_hyp, x, y, z):
     return nlml, fz, cov
 
 
+def nlml_gradient(log_hyp, x, y):
+    """d nlml / d log_hyp of GPr.py:57-69 (analytic; the reference has no gradient, so this row is pinned by
+    central differences of compute_likelihood_verbatim in tests/test_oracle_golden.py, not by a fixture).
+
+    d nlml / d t = 1/2 tr((Kinv - a a^T) dK/dt), a = Kinv y, with, for Kf = sf2 exp(-r2/2) (GPr.py:102):
+    dK/dlog l_k = Kf * (x_ik - x_jk)^2 / l_k^2,  dK/dlog sf = 2 Kf,  dK/dlog sn = 2 sn2 I.
+    """
+    M, sf2, sn2 = decode_hyp(log_hyp)
+    xs = np.asarray(x, dtype=float).reshape(len(x), -1)
+    n, d = xs.shape
+    K = _k_direct(log_hyp, xs)
+    Kf = K - sn2 * np.eye(n)
+    Kinv = np.linalg.inv(K)
+    a = Kinv @ np.asarray(y, dtype=float).reshape(n)
+    A = Kinv - np.outer(a, a)
+    g = np.zeros(d + 2)
+    for k in range(d):
+        diff = (xs[:, k : k + 1] - xs[:, k : k + 1].T) / M[k]
+        g[k] = 0.5 * np.sum(A * Kf * diff * diff)
+    g[d] = np.sum(A * Kf)
+    g[d + 1] = sn2 * np.trace(A)
+    return g
+
+
 def posterior_verbatim(log_hyp, x, y, z):
     """The reference's cost: one compute_likelihood + one compute_prediction (no sharing)."""
     nlml = compute_likelihood_verbatim(log_hyp, x, y)

@@ -462,3 +462,34 @@ def test_c4_size_on_one_gpu(gpk):
     sn2, sf2 = np.exp(lh[-1]) ** 2, np.exp(lh[-2]) ** 2
     np.testing.assert_allclose(y[-256:] - mean, sn2 * alpha[-256:, 0], rtol=0, atol=1e-8)
     assert np.all(var > -1e-9) and np.all(var <= sf2 + 1e-12)
+
+
+# ----------------------------------------------------------------------------- nlml gradient
+@pytest.mark.parametrize("N,d,seed", [(5, 1, 0), (130, 2, 1), (700, 3, 2), (1500, 8, 3), (2500, 5, 4)])
+def test_nlml_gradient_matches_oracle(gpk, N, d, seed):
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+    x, y, _, lh = orc.synthetic_problem(N, d, M=4, seed=seed)
+    lh = lh + 0.1 * np.random.RandomState(seed).randn(d + 2)   # distinct length scales per dimension
+    xin = x[:, 0] if d == 1 else x
+    gp = GPr.GaussianProcess(lh, np.zeros(1), np.zeros(1), "SE", "zero", "zero", xin, y)
+    nlml, grad = gp.compute_likelihood_gradient(lh)
+    ref = orc.nlml_gradient(lh, x, y)
+    assert grad.shape == (d + 2,)
+    np.testing.assert_allclose(grad, ref, rtol=RTOL, atol=RTOL * np.abs(ref).max())
+    np.testing.assert_allclose(nlml.flat[0], orc.compute_likelihood_verbatim(lh, x, y).flat[0], rtol=RTOL)
+
+
+def test_nlml_gradient_descent_step_lowers_nlml(gpk):
+    """Size-independent property at a larger N: a small step against the gradient lowers the nlml by
+    about |g|^2 * step (first-order), which ties the gradient to the HIP nlml itself."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+    x, y, _, lh = orc.synthetic_problem(4096, 4, M=4, seed=9)
+    gp = GPr.GaussianProcess(lh, np.zeros(1), np.zeros(1), "SE", "zero", "zero", x, y)
+    f0, g = gp.compute_likelihood_gradient(lh)
+    step = 1e-4 / np.linalg.norm(g)
+    f1 = gp.compute_likelihood(lh - step * g).flat[0]
+    predicted = -step * float(g @ g)
+    assert f1 < f0.flat[0]
+    assert abs((f1 - f0.flat[0]) - predicted) <= 1e-2 * abs(predicted)

@@ -75,3 +75,18 @@ def test_gppref_oracle_seeded_demo_trace():
     assert lml == pytest.approx(40.5831069552, rel=1e-9)
     np.testing.assert_allclose(f[:5, 0], [-0.0761991, -1.31395028, 0.59264976, 0.47781206, 1.24381158], atol=5e-8)
     np.testing.assert_allclose([t[0] for t in tr[:4]], [1.137, 0.2108, 8.14e-3, 1.20e-5], rtol=2e-3)
+
+
+@pytest.mark.parametrize("N,d,seed", [(40, 1, 0), (60, 3, 1), (90, 8, 2)])
+def test_oracle_gradient_matches_central_differences(N, d, seed):
+    """The reference has no gradient; the analytic oracle is pinned on the reference-restated nlml
+    (compute_likelihood_verbatim, itself pinned by the golden files) through central differences."""
+    x, y, _, lh = orc.synthetic_problem(N, d, M=4, seed=seed)
+    g = orc.nlml_gradient(lh, x, y)
+    h = 1e-5
+    for k in range(d + 2):
+        e = np.zeros(d + 2)
+        e[k] = h
+        fd = (orc.compute_likelihood_verbatim(lh + e, x, y).flat[0]
+              - orc.compute_likelihood_verbatim(lh - e, x, y).flat[0]) / (2 * h)
+        assert abs(g[k] - fd) <= 1e-6 * max(1.0, abs(fd))
