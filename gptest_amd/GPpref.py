@@ -119,6 +119,7 @@ class PreferenceGaussianProcess(object):
         self.last_iterations = 0
         self.last_eps = None
         self.last_trace = None
+        self._mode = None
 
     def calc_laplace(self, loghyp, f=None):
         """GPpref.py:112-157 -> (f (nx,1), lml)."""
@@ -155,10 +156,28 @@ class PreferenceGaussianProcess(object):
         _lib.check(rc, "gpk_pref_laplace")
         self.last_iterations = iters.value
         self.last_trace = trace[:iters.value].copy()
+        self._mode = (handle, uvi, y, fv.copy())   # kept in HBM / on the host for predict_latent
         if self.verbose:
             for e in self.last_trace:
                 print(e)
         return fv.reshape(self._nx, 1), lml.value
+
+    def predict_latent(self, x_test):
+        """Extension (the reference stops at the mode, GPpref.py:157): latent posterior at ``x_test`` (M, d)
+        under the Laplace approximation of the last ``calc_laplace`` -> (mean (M,), var (M,)).
+        ``mean = k*^T (K+eps I)^-1 f``, ``var = k** - k*^T (K + eps I + W^-1)^-1 k*`` (R&W eq. 3.21, 3.24)."""
+        if getattr(self, "_mode", None) is None:
+            raise RuntimeError("predict_latent needs a calc_laplace first")
+        handle, uvi, y, fv = self._mode
+        Z = np.ascontiguousarray(np.asarray(x_test, dtype=np.float64).reshape(-1, self._xdim))
+        mean, mp = _lib.out_array(Z.shape[0])
+        var, vp = _lib.out_array(Z.shape[0])
+        rc = _lib.lib().gpk_pref_predict(handle.ptr, uvi.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+                                         y.ctypes.data_as(_lib.c_double_p), len(y), float(self.likelihood.sigma),
+                                         fv.ctypes.data_as(_lib.c_double_p), Z.ctypes.data_as(_lib.c_double_p),
+                                         Z.shape[0], mp, vp)
+        _lib.check(rc, "gpk_pref_predict")
+        return mean, var
 
     def calc_nlml(self, loghyp):
         """GPpref.py:159-161."""

@@ -650,12 +650,10 @@ static int predict_update(gpk_model* m, int p, int Mpad, int cg0, int ncols, dou
   return launch_gemm_auto(g, s);
 }
 
-int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, double* dV, double* dmean,
-                   double* dvar) {
+// V = R L^-T for Mpad rows (multiple of 128) of width Npad, R destroyed; s_main carries the result.
+int rows_forward_solve(gpk_model* m, int Mpad, double* dR, double* dV) {
   hipStream_t sm = G.s_main, sp = G.s_panel;
   const int np_ = m->Npad, nP = m->nP;
-  timer_begin("predict", sm);
-  GPK_TRY(launch_se_build(dZ, M, Mpad, m->dX, m->N, np_, m->se, 0, 0, dR, np_, 0, sm));
   if (!G.lookahead || nP < 3) {
     for (int p = 0; p < nP; ++p) {
       GPK_TRY(predict_diag(m, p, Mpad, dR, dV, sm));
@@ -688,6 +686,16 @@ int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, 
     }
     GPK_HIP(hipStreamWaitEvent(sm, ev_diag[nP - 1], 0));
   }
+  return 0;
+}
+
+int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, double* dV, double* dmean,
+                   double* dvar) {
+  hipStream_t sm = G.s_main;
+  const int np_ = m->Npad;
+  timer_begin("predict", sm);
+  GPK_TRY(launch_se_build(dZ, M, Mpad, m->dX, m->N, np_, m->se, 0, 0, dR, np_, 0, sm));
+  GPK_TRY(rows_forward_solve(m, Mpad, dR, dV));
   GPK_TRY(launch_row_stats(dV, np_, M, np_, m->dw, m->se.sf2, dmean, dvar, sm));
   timer_end("predict", sm);
   return 0;

@@ -92,6 +92,8 @@ int launch_pref_pair_stats(const long long* uvi, const double* y, const double* 
 int launch_pref_pair_t(const long long* uvi, const double* f, const double* c, const double* q, int npairs, double* t, hipStream_t s);
 int launch_pref_scatter(const long long* uvi, const double* t, const double* scale, int do_sqrt, int npairs, double* out, hipStream_t s);
 int launch_pref_gather(const long long* uvi, const double* x, const double* c, int npairs, double* r, hipStream_t s);
+int launch_pref_gather_rows(const long long* uvi, const double* R, long ldr, const double* c, int npairs, int rows,
+                             int rows_pad, int npad, double* U, long ldu, hipStream_t s);
 int launch_pref_build_S(const double* K, long ldk, const long long* uvi, int npairs, double* S, long lds_, hipStream_t s);
 int launch_pref_build_B(const double* S, long lds_, const double* c, int npairs, int npad, double* B, long ldb, hipStream_t s);
 int launch_maxabsdiff(const double* a, const double* b, int n, double* out, hipStream_t s);

@@ -114,3 +114,89 @@ extern "C" int gpk_pref_laplace(gpk_model* m, const long long* uvi, const double
   model_destroy(mb);
   return rc;
 }
+
+// Latent posterior at test inputs under the Laplace approximation (Rasmussen & Williams eq. 3.21/3.24; the
+// reference stops at the mode, GPpref.py:157 -- SURVEY 8(f) item 2 asks for this as the next step):
+//   mean* = k*^T Ke^-1 f,   var* = k** - k*^T (Ke + W^-1)^-1 k* = k** - u^T B^-1 u,  u = C^1/2 D k*,
+// with Ke = K + eps I as factored by gpk_fit, W = D^T C D at f, B = I + C^1/2 (D Ke D^T) C^1/2: the same
+// npairs x npairs system as one Newton step, so K is never inverted here either.
+extern "C" int gpk_pref_predict(gpk_model* m, const long long* uvi, const double* y, int npairs, double sigma,
+                                const double* f_hat, const double* Z, int M, double* mean_out, double* var_out) {
+  GPK_TRY(rt_require());
+  if (!m || !uvi || !y || !f_hat || !Z || !mean_out || !var_out) return gpk_set_err(-1, "gpk_pref_predict: null pointer");
+  if (!m->dKcopy) return gpk_set_err(-1, "gpk_pref_predict: fit the model with the keep-K flag");
+  if (m->P != 1) return gpk_set_err(-1, "gpk_pref_predict: single-GPU models only");
+  if (npairs < 1 || M < 1 || !(sigma > 0.0)) return gpk_set_err(-1, "gpk_pref_predict: bad arguments");
+  const int nx = m->N, np_ = m->Npad, d = m->d;
+  for (int i = 0; i < 2 * npairs; ++i)
+    if (uvi[i] < 0 || uvi[i] >= nx) return gpk_set_err(-1, "gpk_pref_predict: pair index %lld outside 0..%d", uvi[i], nx - 1);
+  hipStream_t s = G.s_main;
+  gpk_model* mb = nullptr;
+  GPK_TRY(model_create(&mb, npairs, 1, false, 1, 0));
+  const int nbp = mb->Npad, Mpad = round_up(M, 128);
+  long long* duvi = nullptr;
+  double *dy = nullptr, *df = nullptr, *dc = nullptr, *dS = nullptr, *dZ = nullptr, *dR = nullptr, *dU = nullptr, *dV = nullptr,
+         *dzero = nullptr, *dmean = nullptr, *dvar = nullptr, *dtmp = nullptr;
+  int rc = 0;
+  rc |= dev_alloc_t(&duvi, (size_t)2 * npairs);
+  rc |= dev_alloc_t(&dy, (size_t)npairs);
+  rc |= dev_alloc_t(&df, (size_t)np_);
+  rc |= dev_alloc_t(&dc, (size_t)npairs);
+  rc |= dev_alloc_t(&dS, (size_t)npairs * nbp);
+  rc |= dev_alloc_t(&dZ, (size_t)M * d);
+  rc |= dev_alloc_t(&dR, (size_t)Mpad * np_);
+  rc |= dev_alloc_t(&dU, (size_t)Mpad * nbp);
+  rc |= dev_alloc_t(&dV, (size_t)Mpad * nbp);
+  rc |= dev_alloc_t(&dzero, (size_t)nbp);
+  rc |= dev_alloc_t(&dmean, (size_t)Mpad);
+  rc |= dev_alloc_t(&dvar, (size_t)Mpad);
+  rc |= dev_alloc_t(&dtmp, (size_t)Mpad);
+  const double isq = 1.0 / (sigma * std::sqrt(2.0));
+#define PREF_HIP(x)                                                                         \
+  if (!rc && (x) != hipSuccess) rc = gpk_set_err(-2, "%s failed: %s", #x, hipGetErrorString(hipGetLastError()))
+#define PREF_DO(x) \
+  if (!rc) rc = (x)
+  PREF_HIP(hipMemcpyAsync(duvi, uvi, (size_t)2 * npairs * 8, hipMemcpyHostToDevice, s));
+  PREF_HIP(hipMemcpyAsync(dy, y, (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+  PREF_HIP(hipMemsetAsync(df, 0, (size_t)np_ * 8, s));
+  PREF_HIP(hipMemcpyAsync(df, f_hat, (size_t)nx * 8, hipMemcpyHostToDevice, s));
+  PREF_HIP(hipMemcpyAsync(dZ, Z, (size_t)M * d * 8, hipMemcpyHostToDevice, s));
+  PREF_HIP(hipMemsetAsync(dzero, 0, (size_t)nbp * 8, s));
+  // B at f and its factor
+  PREF_DO(launch_pref_pair_stats(duvi, dy, df, npairs, isq, nullptr, nullptr, dc, nullptr, s));
+  PREF_DO(launch_pref_build_S(m->dKcopy, np_, duvi, npairs, dS, nbp, s));
+  PREF_DO(launch_pref_build_B(dS, nbp, dc, npairs, nbp, mb->dK, mb->ldk, s));
+  PREF_DO(potrf_device(mb));
+  // k* rows, mean* = Kzx (Ke^-1 f)
+  PREF_DO(launch_se_build(dZ, M, Mpad, m->dX, nx, np_, m->se, 0, 0, dR, np_, 0, s));
+  PREF_DO(trsv_forward(m, df));
+  PREF_DO(trsv_backward(m, df));
+  PREF_DO(launch_gemv(dR, np_, M, np_, df, dmean, 1.0, 0.0, s));
+  // u rows, V = U Lb^-T, var* = sf2 - |V_j|^2
+  PREF_DO(launch_pref_gather_rows(duvi, dR, np_, dc, npairs, M, Mpad, nbp, dU, nbp, s));
+  PREF_DO(rows_forward_solve(mb, Mpad, dU, dV));
+  PREF_DO(launch_row_stats(dV, nbp, M, nbp, dzero, m->se.sf2, dtmp, dvar, s));
+  int binfo = 0;
+  PREF_HIP(hipMemcpyAsync(&binfo, mb->dinfo, 4, hipMemcpyDeviceToHost, s));
+  PREF_HIP(hipMemcpyAsync(mean_out, dmean, (size_t)M * 8, hipMemcpyDeviceToHost, s));
+  PREF_HIP(hipMemcpyAsync(var_out, dvar, (size_t)M * 8, hipMemcpyDeviceToHost, s));
+  PREF_HIP(hipStreamSynchronize(s));
+  if (!rc && binfo > 0) rc = gpk_set_err(-4, "gpk_pref_predict: B lost positive definiteness (minor %d)", binfo);
+#undef PREF_HIP
+#undef PREF_DO
+  dev_free(duvi, (size_t)2 * npairs * 8);
+  dev_free(dy, (size_t)npairs * 8);
+  dev_free(df, (size_t)np_ * 8);
+  dev_free(dc, (size_t)npairs * 8);
+  dev_free(dS, (size_t)npairs * nbp * 8);
+  dev_free(dZ, (size_t)M * d * 8);
+  dev_free(dR, (size_t)Mpad * np_ * 8);
+  dev_free(dU, (size_t)Mpad * nbp * 8);
+  dev_free(dV, (size_t)Mpad * nbp * 8);
+  dev_free(dzero, (size_t)nbp * 8);
+  dev_free(dmean, (size_t)Mpad * 8);
+  dev_free(dvar, (size_t)Mpad * 8);
+  dev_free(dtmp, (size_t)Mpad * 8);
+  model_destroy(mb);
+  return rc;
+}

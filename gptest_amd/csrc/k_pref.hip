@@ -55,6 +55,19 @@ __global__ void pref_gather_kernel(const long long* __restrict__ uvi, const doub
   r[p] = sqrt(c[p]) * (x[uvi[2 * p + 1]] - x[uvi[2 * p]]);
 }
 
+// U[j][p] = sqrt(c_p) * (R[j][v_p] - R[j][u_p]) for j < rows, p < npairs; zero on the padding (rows_pad x npad)
+__global__ void pref_gather_rows_kernel(const long long* __restrict__ uvi, const double* __restrict__ R, long ldr,
+                                        const double* __restrict__ c, int npairs, int rows, int npad,
+                                        double* __restrict__ U, long ldu) {
+  const int j = blockIdx.y;
+  const double* Rj = R + (long)j * ldr;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npad; p += gridDim.x * blockDim.x) {
+    double v = 0.0;
+    if (j < rows && p < npairs) v = sqrt(c[p]) * (Rj[uvi[2 * p + 1]] - Rj[uvi[2 * p]]);
+    U[(long)j * ldu + p] = v;
+  }
+}
+
 // S[p][q] = K[v_p,v_q] - K[v_p,u_q] - K[u_p,v_q] + K[u_p,u_q]   (D K D^T; K symmetric, full copy)
 __global__ void pref_build_S_kernel(const double* __restrict__ K, long ldk, const long long* __restrict__ uvi,
                                     int npairs, double* __restrict__ S, long lds_) {
@@ -134,6 +147,13 @@ int launch_pref_scatter(const long long* uvi, const double* t, const double* sca
 }
 int launch_pref_gather(const long long* uvi, const double* x, const double* c, int npairs, double* r, hipStream_t s) {
   hipLaunchKernelGGL(pref_gather_kernel, PREF_GRID(npairs), 0, s, uvi, x, c, npairs, r);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+int launch_pref_gather_rows(const long long* uvi, const double* R, long ldr, const double* c, int npairs, int rows,
+                             int rows_pad, int npad, double* U, long ldu, hipStream_t s) {
+  const int gx = (npad + 255) / 256 > 16 ? 16 : (npad + 255) / 256;
+  hipLaunchKernelGGL(pref_gather_rows_kernel, dim3(gx, rows_pad), dim3(256), 0, s, uvi, R, ldr, c, npairs, rows, npad, U, ldu);
   GPK_HIP(hipGetLastError());
   return 0;
 }

@@ -107,6 +107,12 @@ int gpk_free(gpk_model* h);
 int gpk_pref_laplace(gpk_model* h, const long long* uvi, const double* y, int npairs, double sigma,
                      double* f_inout, double delta_f, int max_iter, double* lml_out, int* iters_out,
                      double* ferr_trace);
+/* Latent posterior at M test inputs Z (M, d) under the Laplace approximation at f_hat (the mode gpk_pref_laplace
+ * returned): mean = k*^T (K+eps I)^-1 f_hat, var = k** - k*^T (K + eps I + W^-1)^-1 k*.  The reference stops at
+ * the mode (GPpref.py:157) and never predicts; SURVEY 8(f) item 2 names this as the next step.  Same handle and
+ * pair arguments as gpk_pref_laplace. */
+int gpk_pref_predict(gpk_model* h, const long long* uvi, const double* y, int npairs, double sigma,
+                     const double* f_hat, const double* Z, int M, double* mean_out, double* var_out);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------- */
 /* HIP-event timings (ms) of the stages of the last gpk_fit / gpk_predict on this

@@ -121,6 +121,29 @@ def calc_laplace(x_train, uvi_train, y_train, loghyp, f=None, delta_f=1e-6, max_
     return f, lml, it, eps
 
 
+def predict_latent(x_train, uvi_train, y_train, loghyp, f_hat, eps, x_test):
+    """Latent Laplace posterior at x_test (Rasmussen & Williams eq. 3.21 / 3.24); the reference stops at the mode
+    (GPpref.py:157), so this row has no reference output at all: PARITY UNPINNED, dense textbook algebra.
+
+    mean = k*^T Ke^-1 f,  var = k** - k*^T (I + W Ke)^-1 W k*   (= k** - k*^T (Ke + W^-1)^-1 k*, W singular).
+    """
+    xdim = x_train.shape[1]
+    nx = x_train.shape[0]
+    lik = PrefProbit()
+    lengthscale = np.exp(loghyp[0:xdim])
+    variance = (np.exp(loghyp[xdim])) ** 2
+    Ke = rbf_ard_K(x_train, lengthscale, variance) + eps * np.eye(nx)
+    xs = np.asarray(x_train, dtype=float) / lengthscale
+    zs = np.asarray(x_test, dtype=float).reshape(-1, xdim) / lengthscale
+    d2 = ((xs[:, None, :] - zs[None, :, :]) ** 2).sum(axis=2)
+    Ks = variance * np.exp(-0.5 * d2)                      # (nx, M)
+    W, _ = lik.derivatives(uvi_train, y_train, np.asarray(f_hat, dtype=float).reshape(nx, 1))
+    mean = Ks.T @ np.linalg.solve(Ke, np.asarray(f_hat, dtype=float).reshape(nx))
+    T = np.linalg.solve(np.eye(nx) + W @ Ke, W @ Ks)
+    var = variance - np.einsum("ij,ij->j", Ks, T)
+    return mean, var
+
+
 def demo_problem(n_train=20, true_sigma=0.05, seed=1, d=1):
     """Inputs exactly as GP_preference_demo.py:7-44 for d=1; x@1/d sine for d>1."""
     np.random.seed(seed)

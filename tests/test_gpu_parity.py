@@ -510,3 +510,41 @@ def test_lbfgs_with_gradient_reaches_the_demo_optimum(gpk):
     assert f <= -3.013231 + 2e-5
     np.testing.assert_allclose(hyp, [-1.28291371, 0.42272255, -2.33243027], atol=2e-3)
     assert calls < 80
+
+
+# ----------------------------------------------------------------------------- preference prediction
+@pytest.mark.parametrize("nx,d,M", [(40, 1, 100), (300, 2, 77), (1024, 4, 200)])
+def test_gppref_predict_latent_matches_oracle(gpk, nx, d, M):
+    """PARITY UNPINNED: the reference never predicts from the preference GP (GPpref.py:157 returns the mode);
+    checked against the dense textbook algebra of oracle/gppref_oracle.predict_latent at the same mode."""
+    from gptest_amd import GPpref
+    from oracle import gppref_oracle as po
+
+    x, uvi, y = po.demo_problem(n_train=nx // 2, seed=4, d=d)
+    lh = np.log([0.3] * d + [1.0, 0.1])
+    gp = GPpref.PreferenceGaussianProcess(x, uvi, y, delta_f=1e-8)
+    f, _ = gp.calc_laplace(lh)
+    z = np.random.RandomState(nx).rand(M, d)
+    mean, var = gp.predict_latent(z)
+    mo, vo = po.predict_latent(x, uvi, y, lh, f, gp.last_eps, z)
+    assert mean.shape == var.shape == (M,)
+    np.testing.assert_allclose(mean, mo, rtol=0, atol=1e-6 * np.abs(mo).max())
+    np.testing.assert_allclose(var, vo, rtol=0, atol=1e-6 * np.abs(vo).max())
+    assert np.all(var > -1e-9) and np.all(var <= np.exp(lh[d]) ** 2 + 1e-12)
+
+
+def test_gppref_predict_latent_reproduces_mode_at_training_points(gpk):
+    """Size-independent property: predicting at the training inputs returns the mode itself up to the jitter
+    (k*^T Ke^-1 f = f - eps Ke^-1 f), and preferences order the means (u preferred over v => mean moves)."""
+    from gptest_amd import GPpref
+    from oracle import gppref_oracle as po
+
+    x, uvi, y = po.demo_problem(n_train=400, seed=6, d=2)
+    lh = np.log([0.3, 0.3, 1.0, 0.1])
+    gp = GPpref.PreferenceGaussianProcess(x, uvi, y, delta_f=1e-8)
+    f, _ = gp.calc_laplace(lh)
+    mean, var = gp.predict_latent(x)
+    # residual eps * Ke^-1 f, with Ke^-1 f = grad log p(y|f) at the mode (bounded by the pair count per point)
+    assert np.max(np.abs(mean - f.ravel())) < 1e-3 * np.abs(f).max()
+    with pytest.raises(RuntimeError):
+        GPpref.PreferenceGaussianProcess(x, uvi, y).predict_latent(x)
