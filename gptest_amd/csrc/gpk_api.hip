@@ -79,14 +79,8 @@ int gpk_init(int device) {
       (void)hipGetLastError();
       if (G.s_main) (void)hipStreamDestroy(G.s_main);
       if (G.s_pred) (void)hipStreamDestroy(G.s_pred);
-  G.s_pred = nullptr;
-  if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
-  if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
-  for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
-  G.ev_ring.clear();
-  for (hipEvent_t e : G.ev_pool) (void)hipEventDestroy(e);
-  G.ev_pool.clear();
-      if (G.s_pred) (void)hipStreamDestroy(G.s_pred);
+      if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
+      if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
       G.s_main = G.s_panel = G.s_leaf = G.s_pred = nullptr;
     }
   }
@@ -1001,6 +995,7 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
   GemmNT g{};
   g.A = dA; g.lda = k; g.B = lower ? dA : dB; g.ldb = k; g.C = dC; g.ldc = n;
   g.m = m; g.n = n; g.k = k; g.sub = 1; g.lower = lower & 1;
+  g.xcd_sq = G.xcd_sq;
   extern int g_gemm_variant;
   const int saved_variant = g_gemm_variant;
   if (tile == 4) g_gemm_variant = 4;
