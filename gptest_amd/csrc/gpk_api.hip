@@ -165,6 +165,8 @@ int gpk_set_option(const char* key, double value) {
     G.xcd_sq = (int)value;
   } else if (k == "leaf_direct_rows") {
     G.leaf_direct_rows = (int)value;
+  } else if (k == "pipe_interleave") {
+    G.pipe_interleave = (int)value;
   } else if (k == "fuse_predict") {
     G.fuse_predict = (int)value;
   } else if (k == "timing") {

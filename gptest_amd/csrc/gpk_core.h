@@ -3,6 +3,7 @@
 // the model handle and the blocked-Cholesky driver.
 #pragma once
 #include "gpk_internal.h"
+#include <functional>
 #include <map>
 
 struct StageTimer {
@@ -34,6 +35,7 @@ struct Runtime {
   double last_potrf_enqueue_ms = 0.0, last_pipe_enqueue_ms = 0.0;  // host time spent queueing the last factorisation
   int timing = 0;
   int leaf_direct_rows = 3072;  // leaf goes on the chain stream (no reserved-CU hop) once this few rows remain
+  int pipe_interleave = 0;  // 1: host submits panel p's substitutions right after panel p (0: after the whole factorisation)
   int fuse_predict = 1;  // bench / compute_prediction: overlap the prediction solve with the factorisation tail
   int xcd_sq = 1;              // XCD-aware 8x8-tile square order in the big GEMMs
   int ncu = 256;         // CUs available to the GEMM streams
@@ -90,7 +92,7 @@ struct FusedPredict {
 };
 int fit_device(gpk_model* m, const FusedPredict* fp = nullptr);  // K build + potrf + w + scalars (inputs resident)
 extern int g_potrf_lookahead_used;  // 1 if the last potrf_device recorded per-panel events in G.ev_pool[0..nP)
-int potrf_device(gpk_model* m);                                 // dK -> dL, dDinv
+int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel = nullptr);                                 // dK -> dL, dDinv
 int ensure_ev_pool(int n);                                      // dependency events of the look-ahead schedules
 int build_K(gpk_model* m);                                      // dX -> dK (local block columns)
 int factor_panel(gpk_model* m, int p, hipStream_t s);          // owner only

@@ -336,7 +336,7 @@ int ensure_ev_pool(int n) {
 // leaf/panel kernels leave the critical path.
 static int potrf_distributed(gpk_model* m);
 
-int potrf_device(gpk_model* m) {
+int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   hipStream_t sm = G.s_main, sp = G.s_panel;
   GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
   const int nP = m->nP;
@@ -364,6 +364,7 @@ int potrf_device(gpk_model* m) {
   GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
   GPK_TRY(factor_panel(m, 0, sp));
   GPK_HIP(hipEventRecord(ev_panel[0], sp));
+  if (after_panel) GPK_TRY((*after_panel)(0));
   for (int p = 0; p < nP; ++p) {
     const int r0 = m->pc0[p] + m->pw[p];             // first row/col of the trailing matrix
     const int wn = (p + 1 < nP) ? m->pw[p + 1] : 0;  // width of the look-ahead block column
@@ -373,6 +374,7 @@ int potrf_device(gpk_model* m) {
       GPK_TRY(panel_update(m, p, r0, r0, wn, 0, sp));
       GPK_TRY(factor_panel(m, p + 1, sp));
       GPK_HIP(hipEventRecord(ev_panel[p + 1], sp));
+      if (after_panel) GPK_TRY((*after_panel)(p + 1));
     }
     // (b) s_main: the rest of the trailing matrix (lower triangle starting after block column p+1)
     GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
@@ -521,22 +523,34 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     ev_kb = G.ev_pool[2 * m->nP + 2];
     GPK_HIP(hipEventRecord(ev_kb, s));
   }
-  const auto host_t0 = std::chrono::steady_clock::now();
-  GPK_TRY(potrf_device(m));
-  G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-  timer_end("potrf", s);
-  // Everything that only needs panels <= p is queued on s_pred behind the per-panel events of the
+  // Everything that only needs panels <= p goes to s_pred / s_comm behind the per-panel events of the
   // factorisation: the forward substitution w = L^-1 y (two tiny kernels per panel) and, for a fused
   // fit+predict, the forward substitution of the prediction.  While the trailing updates saturate the
   // chip this merely re-orders work; in the latency-bound tail of the factorisation it fills idle CUs.
-  const auto host_t1 = std::chrono::steady_clock::now();
-  const bool pipelined = g_potrf_lookahead_used && G.s_pred && m->P == 1 && G.fuse_predict;
+  // The host submits panel p's substitutions right after panel p itself (hook below), not after the whole
+  // factorisation.
+  const bool pipelined = G.s_pred && m->P == 1 && G.fuse_predict && G.lookahead && m->nP >= 3 && (m->has_y || fuse);
   bool fused_done = false;
-  if (pipelined && (m->has_y || fuse)) {
-    hipStream_t sq = G.s_pred;
+  hipStream_t sq = G.s_pred;
+  hipStream_t sy = G.s_comm ? G.s_comm : sq;  // the y substitution gets its own stream (idle on a single GPU)
+  std::function<int(int)> hook = [&](int p) -> int {
     hipEvent_t* ev_panel = G.ev_pool.data();
+    const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
+    if (m->has_y) {
+      double* Lp = m->Lpanel(p);
+      GPK_HIP(hipStreamWaitEvent(sy, ev_panel[p], 0));
+      GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, m->dw + c0, 0, sy));
+      GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, m->dw + c0, m->dw + c0 + w, sy));
+    }
+    if (fuse) {
+      GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
+      GPK_TRY(predict_diag(m, p, fp->Mpad, fp->dR, fp->dV, sq));
+      GPK_TRY(predict_update(m, p, fp->Mpad, c0 + w, np_ - c0 - w, fp->dR, fp->dV, sq));
+    }
+    return 0;
+  };
+  if (pipelined) {
     if (!ev_kb) return gpk_set_err(-1, "internal: pipeline start event missing");
-    hipStream_t sy = G.s_comm ? G.s_comm : sq;  // the y substitution gets its own stream (idle on a single GPU)
     GPK_HIP(hipStreamWaitEvent(sq, ev_kb, 0));
     if (sy != sq) GPK_HIP(hipStreamWaitEvent(sy, ev_kb, 0));
     if (m->has_y) GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, sy));
@@ -544,20 +558,16 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
       timer_begin("predict", sq);
       GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq));
     }
-    for (int p = 0; p < m->nP; ++p) {
-      const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
-      if (m->has_y) {
-        double* Lp = m->Lpanel(p);
-        GPK_HIP(hipStreamWaitEvent(sy, ev_panel[p], 0));
-        GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, m->dw + c0, 0, sy));
-        GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, m->dw + c0, m->dw + c0 + w, sy));
-      }
-      if (fuse) {
-        GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
-        GPK_TRY(predict_diag(m, p, fp->Mpad, fp->dR, fp->dV, sq));
-        GPK_TRY(predict_update(m, p, fp->Mpad, c0 + w, np_ - c0 - w, fp->dR, fp->dV, sq));
-      }
-    }
+  }
+  const auto host_t0 = std::chrono::steady_clock::now();
+  GPK_TRY(potrf_device(m, (pipelined && G.pipe_interleave) ? &hook : nullptr));
+  G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+  timer_end("potrf", s);
+  const auto host_t1 = std::chrono::steady_clock::now();
+  if (pipelined) {
+    if (!g_potrf_lookahead_used) return gpk_set_err(-1, "internal: pipelined substitutions without look-ahead");
+    if (!G.pipe_interleave)
+      for (int p = 0; p < m->nP; ++p) GPK_TRY(hook(p));
     if (fuse) {
       timer_end("predict", sq);
       fused_done = true;
@@ -575,7 +585,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   GPK_TRY(launch_sum_log_diag(m->dDinv, m->N, m->dscal + 0, s));
   if (m->has_y) {
     timer_begin("solve_y", s);
-    if (!(pipelined && (m->has_y || fuse))) {
+    if (!pipelined) {
       GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, s));
       GPK_TRY(trsv_forward(m, m->dw));
     }
