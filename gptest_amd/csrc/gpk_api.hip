@@ -70,15 +70,21 @@ int gpk_init(int device) {
       // s_pred (forward substitutions pipelined behind the panels): priority instead of a mask, otherwise its
       // kernels queue behind thousands of trailing-update workgroups and the whole backlog (2.7 ms measured)
       // is left over when the factorisation ends.  GPK_PRED_PRIO=0 restores the masked stream.
+      // The y substitution shares this stream.  Stream COUNT matters on this part: with the y chain on a stream
+      // of its own the posterior rate at N = 16384 was 23.6 (high priority) / 24.8 (normal) against 25.6 here,
+      // one further idle high-priority stream took it to 19-20, and moving the substitutions onto the panel
+      // chain's stream (three streams) to 22.4: four streams -- update, leaf, panel chain, substitutions.
       const char* env_qp = getenv("GPK_PRED_PRIO");
       if (env_qp && env_qp[0] == '0') e3 = hipExtStreamCreateWithCUMask(&G.s_pred, words, m_all.data());
+      else if (env_qp && env_qp[0] == '2') e3 = hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, (plo + phi) / 2);
+      else if (env_qp && env_qp[0] == '3') e3 = hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, plo);
       else e3 = hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, phi);
     }
     masked = (e3 == hipSuccess);
     if (!masked) {
       (void)hipGetLastError();
       if (G.s_main) (void)hipStreamDestroy(G.s_main);
-      if (G.s_pred) (void)hipStreamDestroy(G.s_pred);
+      if (G.s_pred && G.s_pred != G.s_panel) (void)hipStreamDestroy(G.s_pred);
       if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
       if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
       G.s_main = G.s_panel = G.s_leaf = G.s_pred = nullptr;
@@ -94,7 +100,6 @@ int gpk_init(int device) {
   }
   G.cu_reserved = masked;
   G.ncu = masked ? ncu - 8 : ncu;
-  GPK_HIP(hipStreamCreateWithPriority(&G.s_comm, hipStreamNonBlocking, hi));
   for (int i = 0; i < 64; ++i) {
     hipEvent_t e;
     GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -116,7 +121,7 @@ void gpk_shutdown(void) {
   for (hipEvent_t e : G.ev_free) (void)hipEventDestroy(e);
   G.ev_free.clear();
   if (G.s_main) (void)hipStreamDestroy(G.s_main);
-  if (G.s_pred) (void)hipStreamDestroy(G.s_pred);
+  if (G.s_pred && G.s_pred != G.s_panel) (void)hipStreamDestroy(G.s_pred);
   G.s_pred = nullptr;
   if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
   if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
@@ -124,8 +129,7 @@ void gpk_shutdown(void) {
   G.ev_ring.clear();
   for (hipEvent_t e : G.ev_pool) (void)hipEventDestroy(e);
   G.ev_pool.clear();
-  if (G.s_comm) (void)hipStreamDestroy(G.s_comm);
-  G.s_main = G.s_panel = G.s_comm = G.s_leaf = nullptr;
+  G.s_main = G.s_panel = G.s_leaf = nullptr;
   G.inited = false;
 }
 

@@ -18,8 +18,8 @@ struct StageTimer {
 struct Runtime {
   bool inited = false;
   int device = 0;
-  hipStream_t s_main = nullptr, s_panel = nullptr, s_comm = nullptr;
-  hipStream_t s_pred = nullptr;   // prediction solve pipelined behind the factorisation (fused fit+predict)
+  hipStream_t s_main = nullptr, s_panel = nullptr;
+  hipStream_t s_pred = nullptr;   // y and prediction substitutions pipelined behind the factorisation (fused fit+predict)
   hipStream_t s_leaf = nullptr;   // CU-masked stream owning one reserved CU for the 1-workgroup leaf kernels
   bool cu_reserved = false;
   std::vector<hipEvent_t> ev_ring;

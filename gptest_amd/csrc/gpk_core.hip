@@ -523,7 +523,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     ev_kb = G.ev_pool[2 * m->nP + 2];
     GPK_HIP(hipEventRecord(ev_kb, s));
   }
-  // Everything that only needs panels <= p goes to s_pred / s_comm behind the per-panel events of the
+  // Everything that only needs panels <= p goes to s_pred behind the per-panel events of the
   // factorisation: the forward substitution w = L^-1 y (two tiny kernels per panel) and, for a fused
   // fit+predict, the forward substitution of the prediction.  While the trailing updates saturate the
   // chip this merely re-orders work; in the latency-bound tail of the factorisation it fills idle CUs.
@@ -532,7 +532,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   const bool pipelined = G.s_pred && m->P == 1 && G.fuse_predict && G.lookahead && m->nP >= 3 && (m->has_y || fuse);
   bool fused_done = false;
   hipStream_t sq = G.s_pred;
-  hipStream_t sy = G.s_comm ? G.s_comm : sq;  // the y substitution gets its own stream (idle on a single GPU)
+  hipStream_t sy = sq;  // one stream for both substitutions (see gpk_init on the stream count)
   std::function<int(int)> hook = [&](int p) -> int {
     hipEvent_t* ev_panel = G.ev_pool.data();
     const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
@@ -543,7 +543,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
       GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, m->dw + c0, m->dw + c0 + w, sy));
     }
     if (fuse) {
-      GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
+      if (!m->has_y || sy != sq) GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
       GPK_TRY(predict_diag(m, p, fp->Mpad, fp->dR, fp->dV, sq));
       GPK_TRY(predict_update(m, p, fp->Mpad, c0 + w, np_ - c0 - w, fp->dR, fp->dV, sq));
     }

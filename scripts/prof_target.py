@@ -19,7 +19,8 @@ l = _lib.lib()
 for o in opts:
     k, v = o.split("=")
     _lib.set_option(k, float(v))
-l.gpk_set_option(b"timing", 1.0)
+if not any(o.startswith("timing=") for o in opts):
+    l.gpk_set_option(b"timing", 1.0)
 X, y, Z, lh = synthetic_problem(N, d, M)
 P = _lib.c_double_p
 ms = ctypes.c_double()
