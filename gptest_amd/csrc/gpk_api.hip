@@ -169,6 +169,12 @@ int gpk_set_option(const char* key, double value) {
     G.xcd_sq = (int)value;
   } else if (k == "leaf_direct_rows") {
     G.leaf_direct_rows = (int)value;
+  } else if (k == "stamps") {
+    G.stamps = (int)value;
+  } else if (k == "pred_small_below") {
+    G.pred_small_below = (int)value;
+  } else if (k == "small_tile_below") {
+    G.small_tile_below = (int)value;
   } else if (k == "pipe_interleave") {
     G.pipe_interleave = (int)value;
   } else if (k == "fuse_predict") {
@@ -190,6 +196,14 @@ double gpk_get_option(const char* key) {
   if (k == "potrf_enqueue_ms") return G.last_potrf_enqueue_ms;
   if (k == "pipe_enqueue_ms") return G.last_pipe_enqueue_ms;
   if (k == "cu_reserved") return G.cu_reserved ? 1.0 : 0.0;
+  // diagnostic stamps of the last fused fit: "stamp_panel_<p>" / "stamp_subst_<p>" in ms after panel 0
+  if (k.rfind("stamp_", 0) == 0 && G.hstamps.size() == 1024 && G.hstamps[0]) {
+    const bool subst = k.rfind("stamp_subst_", 0) == 0;
+    const int p = atoi(k.c_str() + (subst ? 12 : 12));
+    if (p < 0 || p >= 512) return NAN;
+    const unsigned long long v = G.hstamps[(subst ? 512 : 0) + p];
+    return v ? (double)((long long)(v - G.hstamps[0])) * 1e-5 : NAN;
+  }
   return NAN;
 }
 

@@ -298,6 +298,10 @@ int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hi
   g.B = Lp + (long)(c0g - c0) * w; g.ldb = w;
   g.C = m->dK + (long)r0g * np_ + c0g; g.ldc = np_;
   g.m = rows; g.n = ncols; g.k = w; g.sub = 1; g.lower = lower;
+  // Few 128x128 tiles = a latency-bound launch on the panel chain (look-ahead block column, tail of the
+  // factorisation): 64x64 tiles put 4x as many CUs on it (84 tiles at K = 256: 70 us -> 64x64: ~20 us).
+  const long tiles = lower ? (long)(rows / 128) * (rows / 128 + 1) / 2 : (long)(rows / 128) * (ncols / 128);
+  if (tiles < G.small_tile_below) return launch_gemm_nt(g, false, s);
   return launch_gemm_auto(g, s);
 }
 
@@ -364,6 +368,7 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
   GPK_TRY(factor_panel(m, 0, sp));
   GPK_HIP(hipEventRecord(ev_panel[0], sp));
+  if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + 0, sp));
   if (after_panel) GPK_TRY((*after_panel)(0));
   for (int p = 0; p < nP; ++p) {
     const int r0 = m->pc0[p] + m->pw[p];             // first row/col of the trailing matrix
@@ -374,6 +379,7 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
       GPK_TRY(panel_update(m, p, r0, r0, wn, 0, sp));
       GPK_TRY(factor_panel(m, p + 1, sp));
       GPK_HIP(hipEventRecord(ev_panel[p + 1], sp));
+      if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p + 1, sp));
       if (after_panel) GPK_TRY((*after_panel)(p + 1));
     }
     // (b) s_main: the rest of the trailing matrix (lower triangle starting after block column p+1)
@@ -547,6 +553,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
       GPK_TRY(predict_diag(m, p, fp->Mpad, fp->dR, fp->dV, sq));
       GPK_TRY(predict_update(m, p, fp->Mpad, c0 + w, np_ - c0 - w, fp->dR, fp->dV, sq));
     }
+    if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + 512 + p, sq));
     return 0;
   };
   if (pipelined) {
@@ -559,6 +566,11 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
       GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq));
     }
   }
+  if (G.stamps && !G.dstamps && m->nP <= 512) {
+    GPK_HIP(hipMalloc((void**)&G.dstamps, 1024 * 8));
+    G.hstamps.assign(1024, 0);
+  }
+  if (G.stamps && G.dstamps) GPK_HIP(hipMemsetAsync(G.dstamps, 0, 1024 * 8, s));
   const auto host_t0 = std::chrono::steady_clock::now();
   GPK_TRY(potrf_device(m, (pipelined && G.pipe_interleave) ? &hook : nullptr));
   G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
@@ -603,6 +615,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   int hinfo = 0;
   GPK_HIP(hipMemcpyAsync(hs, m->dscal, 16, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s));
+  if (G.stamps && G.dstamps) GPK_HIP(hipMemcpyAsync(G.hstamps.data(), G.dstamps, 1024 * 8, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipStreamSynchronize(s));
   if (m->P > 1 && !m->virtual_rank) {  // only the owner of the failing panel saw it
     double hi = (double)hinfo;
@@ -656,7 +669,7 @@ static int predict_update(gpk_model* m, int p, int Mpad, int cg0, int ncols, dou
   g.C = dR + cg0; g.ldc = np_;
   g.m = Mpad; g.n = ncols; g.k = w; g.sub = 1;
   // few 128x128 tiles (the look-ahead block column): 64x64 tiles put 4x as many CUs on the critical path
-  if ((long)(Mpad / 128) * (ncols / 128) < 96) return launch_gemm_nt(g, false, s);
+  if ((long)(Mpad / 128) * (ncols / 128) < G.pred_small_below) return launch_gemm_nt(g, false, s);
   return launch_gemm_auto(g, s);
 }
 

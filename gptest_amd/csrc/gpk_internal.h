@@ -82,6 +82,7 @@ int launch_gemvT_sub(const double* A, long lda, int m, int k, const double* x, d
 int launch_diag_solve(const double* Lp, int w, const double* Dinv, double* b, int transpose, hipStream_t s);
 int launch_transpose(const double* in, long ldin, int rows, int cols, double* out, long ldout, hipStream_t s);
 int launch_fill(double* p, size_t n, double v, hipStream_t s);
+int launch_stamp(unsigned long long* out, hipStream_t s);
 int launch_set_diag(double* p, long ld, int n, double v, hipStream_t s);
 int launch_unpack_L(const double* Lp, int w, int h, int c0, double* out, long ldout, hipStream_t s);
 int launch_gather2d(const double* K, long ldk, const long long* idx, int nidx, double* out, hipStream_t s);

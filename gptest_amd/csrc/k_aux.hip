@@ -456,3 +456,11 @@ int launch_nlml_grad_terms(const double* X, int N, int d, const double* NK, long
   GPK_HIP(hipGetLastError());
   return 0;
 }
+
+// diagnostic: device-side progress stamp (constant 100 MHz clock), one thread
+__global__ void stamp_kernel(unsigned long long* out) { *out = wall_clock64(); }
+int launch_stamp(unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, out);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
