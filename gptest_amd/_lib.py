@@ -4,6 +4,7 @@ The product path fails loudly: no NumPy/CPU fallback exists anywhere in this
 package.  ``lib()`` raises ``GpkError`` when the shared library is not built and
 ``init()`` raises when no gfx950 device is visible.
 """
+import atexit
 import ctypes
 import os
 
@@ -113,6 +114,9 @@ def check(rc, what):
     raise GpkError("%s failed (%d): %s" % (what, rc, last_error()))
 
 
+_atexit_registered = [False]
+
+
 def init(device=None):
     """Bind this process to one GPU (LOCAL_RANK by default).  Idempotent."""
     global _inited
@@ -126,6 +130,11 @@ def init(device=None):
         raise GpkError("no HIP device visible: the gptest_amd product path needs an MI355X (gfx950); "
                        "there is no CPU fallback")
     check(l.gpk_init(int(device) % n), "gpk_init")
+    if not _atexit_registered[0]:
+        # streams, events and pooled HBM are released before the HIP runtime's own exit handlers run (a profiler
+        # attached to the process otherwise sees live CU-masked queues during its teardown)
+        atexit.register(shutdown)
+        _atexit_registered[0] = True
     _inited = True
 
 
