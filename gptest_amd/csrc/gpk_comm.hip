@@ -55,6 +55,13 @@ int gpk_comm_init(int rank, int nranks, const void* uid128) {
   G.nccl = c;
   G.rank = rank;
   G.nranks = nranks;
+  // the substitution stream is only used by the single-GPU pipeline; an idle extra high-priority queue is not
+  // free on this part (gpk_init comment), so a multi-rank process runs with three: update, leaf, panel/broadcast
+  if (G.s_pred && G.s_pred != G.s_panel) {
+    (void)hipStreamSynchronize(G.s_pred);
+    (void)hipStreamDestroy(G.s_pred);
+  }
+  G.s_pred = nullptr;
   return 0;
 }
 
