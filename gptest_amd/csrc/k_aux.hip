@@ -363,32 +363,34 @@ int launch_set_diag(double* p, long ld, int n, double v, hipStream_t s) {
 //   out[d+1]   : trace(A)                                         (-> d nlml / d log sigma_n / sn2)
 // Kf_ij = sf2 exp(-r2/2) is recomputed on the fly (no second N^2 read).  One workgroup per 128x128 lower tile
 // writes d+2 partial sums (fixed tree), a second kernel adds the tile partials in a fixed order.
-template <int D>
+template <int D>  // D = 0: runtime dimension up to 32 (loops unrolled to 32 and predicated)
 __global__ __launch_bounds__(256) void nlml_grad_tiles_kernel(const double* __restrict__ X, int N,
                                                               const double* __restrict__ NK, long ldk,
                                                               const double* __restrict__ alpha, SEParams p,
                                                               double* __restrict__ partial) {
-  __shared__ double rs[128 * D];
-  __shared__ double cs[128 * D];
+  constexpr int DMAX = (D == 0) ? 32 : D;
+  __shared__ double rs[128 * DMAX];
+  __shared__ double cs[128 * DMAX];
   __shared__ double sm[16];
+  const int d = (D == 0) ? p.d : D;
   const int tc = blockIdx.x, tr = blockIdx.y;
   const int ntile = gridDim.x;
-  double* outp = partial + ((long)tr * ntile + tc) * (D + 2);
+  double* outp = partial + ((long)tr * ntile + tc) * (d + 2);
   const int tid = threadIdx.x;
   if (tc > tr) {
-    if (tid < D + 2) outp[tid] = 0.0;
+    if (tid < d + 2) outp[tid] = 0.0;
     return;
   }
   const int r0 = tr * 128, c0 = tc * 128;
-  for (int e = tid; e < 128 * D; e += 256) {
-    const int i = e / D, k = e - i * D;
-    rs[e] = (r0 + i < N) ? X[(long)(r0 + i) * D + k] / p.ell[k] : 0.0;
-    cs[k * 128 + i] = (c0 + i < N) ? X[(long)(c0 + i) * D + k] / p.ell[k] : 0.0;  // [k][j]: lanes hit distinct banks
+  for (int e = tid; e < 128 * d; e += 256) {
+    const int i = e / d, k = e - i * d;
+    rs[i * DMAX + k] = (r0 + i < N) ? X[(long)(r0 + i) * d + k] / p.ell[k] : 0.0;
+    cs[k * 128 + i] = (c0 + i < N) ? X[(long)(c0 + i) * d + k] / p.ell[k] : 0.0;  // [k][j]: lanes hit distinct banks
   }
   __syncthreads();
-  double acc[D + 2];
+  double acc[DMAX + 2];
 #pragma unroll
-  for (int k = 0; k < D + 2; ++k) acc[k] = 0.0;
+  for (int k = 0; k < DMAX + 2; ++k) acc[k] = 0.0;
   const int lane = tid & 63, w = tid >> 6;
   for (int rr = 0; rr < 32; ++rr) {
     const int i = w * 32 + rr, gi = r0 + i;
@@ -398,11 +400,11 @@ __global__ __launch_bounds__(256) void nlml_grad_tiles_kernel(const double* __re
     for (int h = 0; h < 2; ++h) {
       const int j = lane + 64 * h, gj = c0 + j;
       if (gj >= N || gj > gi) continue;
-      double dk[D];
+      double dk[DMAX];
       double r2 = 0.0;
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const double e = rs[i * D + k] - cs[k * 128 + j];
+      for (int k = 0; k < DMAX; ++k) {
+        const double e = (k < d) ? rs[i * DMAX + k] - cs[k * 128 + j] : 0.0;
         dk[k] = e * e;
         r2 += dk[k];
       }
@@ -411,18 +413,21 @@ __global__ __launch_bounds__(256) void nlml_grad_tiles_kernel(const double* __re
       const double wgt = (gi == gj) ? 1.0 : 2.0;  // symmetric: the strict lower part counts twice
       const double akf = wgt * a * kf;
 #pragma unroll
-      for (int k = 0; k < D; ++k) acc[k] += akf * dk[k];
-      acc[D] += akf;
-      if (gi == gj) acc[D + 1] += a;
+      for (int k = 0; k < DMAX; ++k) acc[k] += akf * dk[k];
+      acc[DMAX] += akf;
+      if (gi == gj) acc[DMAX + 1] += a;
     }
   }
+  // terms 0..d-1, then the two scalar traces, each with the same fixed tree
 #pragma unroll
-  for (int k = 0; k < D + 2; ++k) {
+  for (int k = 0; k < DMAX + 2; ++k) {
+    const int slot = (k < DMAX) ? k : d + (k - DMAX);
+    if (k < DMAX && k >= d) continue;  // uniform
     double v = acc[k];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if (lane == 0) sm[w] = v;
     __syncthreads();
-    if (tid == 0) outp[k] = sm[0] + sm[1] + sm[2] + sm[3];
+    if (tid == 0) outp[slot] = sm[0] + sm[1] + sm[2] + sm[3];
     __syncthreads();
   }
 }
@@ -449,7 +454,9 @@ int launch_nlml_grad_terms(const double* X, int N, int d, const double* NK, long
   switch (d) {
     GPK_GRAD_CASE(1) GPK_GRAD_CASE(2) GPK_GRAD_CASE(3) GPK_GRAD_CASE(4)
     GPK_GRAD_CASE(5) GPK_GRAD_CASE(6) GPK_GRAD_CASE(7) GPK_GRAD_CASE(8)
-    default: return gpk_set_err(-1, "nlml gradient: input dimension d=%d outside 1..8", d);
+    default:
+      if (d < 1 || d > 32) return gpk_set_err(-1, "nlml gradient: input dimension d=%d outside 1..32", d);
+      hipLaunchKernelGGL(nlml_grad_tiles_kernel<0>, grid, block, 0, s, X, N, NK, ldk, alpha, p, partial);
   }
 #undef GPK_GRAD_CASE
   hipLaunchKernelGGL(nlml_grad_final_kernel, dim3(d + 2), dim3(1024), 0, s, partial, (long)nt * nt, d + 2, out);

@@ -91,7 +91,8 @@ int gpk_kmatvec(gpk_model* h, const double* B, int nrhs, double* out);
 int gpk_kgather(gpk_model* h, const long long* idx, int nidx, double* out);
 /* Gradient of the nlml of GPr.py:57-69 with respect to the d+2 log hyper-parameters (same order as log_hyp:
  * d length scales, signal sd, noise sd), re-using the factor of the fit.  The reference has no gradient (its
- * demos hand-set hyp); this is the "next" row of SURVEY 8(f) for fitting hyper-parameters.  Single-GPU models. */
+ * demos hand-set hyp); this is the "next" row of SURVEY 8(f) for fitting hyper-parameters.  Single-GPU models,
+ * d <= 32 like the kernel-matrix builder. */
 int gpk_nlml_grad(gpk_model* h, double* grad_out);
 /* scalars of the last fit: which = 0 nlml, 1 sum log L_ii, 2 y^T K^-1 y, 3 sf2, 4 sn2. */
 int gpk_model_scalar(gpk_model* h, int which, double* out);

@@ -18,7 +18,7 @@ for N, d in [(20, 1), (128, 2), (512, 1), (1024, 4), (2048, 4), (4096, 4), (8192
     t0 = time.perf_counter()
     for i in range(reps):
         gp.compute_likelihood(lh + 1e-7 * (i + 1))     # new hyper-parameters every call: no cache hit
-    t_l = (time.perf_counter() - t0) / reps * 1e3
+    t_l = (time.perf_counter() - t0) / reps * 1e3  # mean; first-use allocations of a new size show up here
     t0 = time.perf_counter()
     for i in range(reps):
         g2 = GPr.GaussianProcess(lh + 1e-7 * (i + 1), 0, 0, "SE", "zero", "zero", xin, y)

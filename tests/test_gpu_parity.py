@@ -465,7 +465,7 @@ def test_c4_size_on_one_gpu(gpk):
 
 
 # ----------------------------------------------------------------------------- nlml gradient
-@pytest.mark.parametrize("N,d,seed", [(5, 1, 0), (130, 2, 1), (700, 3, 2), (1500, 8, 3), (2500, 5, 4)])
+@pytest.mark.parametrize("N,d,seed", [(5, 1, 0), (130, 2, 1), (700, 3, 2), (1500, 8, 3), (2500, 5, 4), (300, 11, 5), (200, 32, 6)])
 def test_nlml_gradient_matches_oracle(gpk, N, d, seed):
     from gptest_amd import GPr
     from oracle import gpr_oracle as orc
