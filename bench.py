@@ -156,7 +156,7 @@ def main():
             pass
         flops = tr_flops / max(args.steps, 1)
         out = {
-            "metric": "GP posterior solves/sec (N=16384, d=8, M=1024; fit + predict sharing one Cholesky)",
+            "metric": "GP posterior solves/sec (N=%d, d=%d, M=%d; fit + predict sharing one Cholesky)" % (N, d, M),
             "value": args.steps / (t_ms * 1e-3),
             "unit": "posteriors/s",
             "n_gpus": world,
@@ -168,8 +168,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "GPr regression N=%d d=%d RBF fp64, M=%d test points (BASELINE configs[2])" % (N, d, M),
-                       "panel_width": nb, "parallelism": "1 GPU" if world == 1 else "block-cyclic panels x%d, RCCL broadcast" % world},
+            "config": {"workload": "GPr regression N=%d d=%d RBF fp64, M=%d test points%s" % (
+                N, d, M, " (BASELINE configs[2], the size the metric is quoted on)" if (N, d) == (16384, 8) else
+                " (BASELINE configs[1])" if (N, d) == (4096, 4) else ""),
+                       "panel_schedule": "512/256/128 columns by remaining size (nb_auto)" if world == 1 else "uniform %d" % nb,
+                       "parallelism": "1 GPU" if world == 1 else "block-cyclic panels x%d, RCCL broadcast" % world},
             "roofline": {"kernel": "gemm_nt8_kernel (Cholesky trailing update, fp64 MFMA 16x16x4)", "bound": "mfma",
                          "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,

@@ -76,22 +76,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
       rb[p] = *reinterpret_cast<const d2*>(Bg + (long)(p * 32 + lrow) * g.ldb + kt * BK + lchk);
     }
   };
+  // sub mode, exactly as in the 8-wave kernel below (so that every kernel of this file rounds identically and the
+  // choice of tile size never changes a bit of the factor): accumulators start as C, A is negated on its way
+  // into LDS, the epilogue only stores.
+  const double sgn = g.sub ? -1.0 : 1.0;
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      *reinterpret_cast<d2*>(As + (buf * BT + p * 32 + lrow) * LDS_LD + lchk) = ra[p];
+      d2 na = {sgn * ra[p].x, sgn * ra[p].y};
+      *reinterpret_cast<d2*>(As + (buf * BT + p * 32 + lrow) * LDS_LD + lchk) = na;
       *reinterpret_cast<d2*>(Bs + (buf * BT + p * 32 + lrow) * LDS_LD + lchk) = rb[p];
     }
   };
 
+  const int nk = g.k / BK;
+  const int fr = lane & 15, fg = lane >> 4;
+  double* Cg = g.C + ((long)ti * BT + wm * WT * 16) * g.ldc + (long)tj * BT + wn * WT * 16;
   d4 acc[WT][WT];
 #pragma unroll
   for (int i = 0; i < WT; ++i)
 #pragma unroll
-    for (int j = 0; j < WT; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-
-  const int nk = g.k / BK;
-  const int fr = lane & 15, fg = lane >> 4;
+    for (int j = 0; j < WT; ++j) {
+      if (g.sub) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = Cg[(long)(i * 16 + fg + 4 * r) * g.ldc + j * 16 + fr];
+      } else {
+        acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+      }
+    }
   gload(0);
   lstore(0);
   __syncthreads();
@@ -117,19 +129,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
   }
 
   // ---- epilogue: C/D layout col = lane&15, row = (lane>>4) + 4*reg
-  double* Cg = g.C + ((long)ti * BT + wm * WT * 16) * g.ldc + (long)tj * BT + wn * WT * 16;
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
 #pragma unroll
     for (int j = 0; j < WT; ++j) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double* p = Cg + (long)(i * 16 + fg + 4 * r) * g.ldc + j * 16 + fr;
-        if (g.sub)
-          *p = *p - acc[i][j][r];
-        else
-          *p = acc[i][j][r];
-      }
+      for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + fg + 4 * r) * g.ldc + j * 16 + fr] = acc[i][j][r];
     }
   }
 }

@@ -5,9 +5,12 @@ import numpy as np
 from gptest_amd import _lib
 from oracle.gpr_oracle import synthetic_problem
 N, d, M = 16384, 8, 1024
+args = sys.argv[1:]
+if args and args[0].isdigit():
+    N = int(args.pop(0)); d = int(args.pop(0))
 _lib.init()
 l = _lib.lib()
-for o in sys.argv[1:]:
+for o in args:
     k, v = o.split("=")
     _lib.set_option(k, float(v))
 _lib.set_option("stamps", 1)
@@ -24,5 +27,5 @@ while True:
     if math.isnan(a): break
     rows.append((p, a, b)); p += 1
 print("panel: chain-done ms / substitutions-done ms / lag")
-print("  ".join("%d: %.1f/%.1f/%.1f" % (p, a, b, b - a) for p, a, b in rows[::3] + rows[-1:]))
+print("  ".join("%d: %.1f/%.1f/%.1f" % (p, a, b, b - a) for p, a, b in rows[::max(1, len(rows) // 20)] + rows[-1:]))
 _lib.shutdown()

@@ -48,6 +48,20 @@ def test_mfma_gemm_nt(gpk, m, n, k, tile, sub, lower):
         np.testing.assert_allclose(C, ref, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("sub", [0, 1])
+def test_tile_sizes_round_identically(gpk, sub):
+    """The schedule picks 64x64 or 128x128 tiles by launch size; the factor must not depend on that choice
+    (the block-cyclic emulation is compared bit for bit with the one-GPU factor)."""
+    rng = np.random.RandomState(11)
+    A, B, C0 = rng.randn(256, 96), rng.randn(384, 96), rng.randn(256, 384)
+    out = []
+    for tile in (64, 128):
+        C = C0.copy()
+        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 256, 384, 96, sub, 0, tile) == 0
+        out.append(C)
+    np.testing.assert_array_equal(out[0], out[1])
+
+
 def test_mfma_fragment_layout_identity(gpk):
     """The f64 MFMA C/D map differs from every other dtype (guide section 3): A = I, asymmetric B."""
     A = np.zeros((128, 16))
