@@ -34,7 +34,7 @@ struct Runtime {
   int lookahead = 1;
   double last_potrf_enqueue_ms = 0.0, last_pipe_enqueue_ms = 0.0;  // host time spent queueing the last factorisation
   int timing = 0;
-  int leaf_direct_rows = 3072;  // leaf goes on the chain stream (no reserved-CU hop) once this few rows remain
+  int leaf_direct_rows = 5120;  // leaf goes on the chain stream (no reserved-CU hop) once this few rows remain
   int stamps = 0;  // diagnostic: device-side progress stamps per panel (gpk_get_option("stamp_lag_*"))
   unsigned long long* dstamps = nullptr;
   std::vector<unsigned long long> hstamps;
