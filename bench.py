@@ -187,9 +187,12 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, d, M)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     _lib.check(l.gpk_comm_barrier(), "barrier")
     l.gpk_comm_destroy()
+    # everything is measured and printed: release the GPU objects explicitly (a profiler attached to this process
+    # needs that for a clean exit), but never let the release keep the process alive
+    _lib.shutdown(full=True, watchdog_s=20.0)
 
 
 if __name__ == "__main__":

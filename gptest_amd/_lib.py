@@ -133,16 +133,40 @@ def init(device=None):
     if not _atexit_registered[0]:
         # streams, events and pooled HBM are released before the HIP runtime's own exit handlers run (a profiler
         # attached to the process otherwise sees live CU-masked queues during its teardown)
-        atexit.register(shutdown)
+        atexit.register(_shutdown_at_exit)
         _atexit_registered[0] = True
     _inited = True
 
 
-def shutdown():
+def shutdown(full=True, watchdog_s=None):
+    """Release streams, events and pooled HBM.  ``full=False`` (what the interpreter-exit handler uses) leaves the
+    CU-masked streams to process teardown: their hipStreamDestroy has been seen to hang in one scenario, and an exit
+    handler must never hang.  ``watchdog_s``: run the release on a helper thread and hard-exit the process with
+    status 0 if it has not returned in time (for scripts whose work is done and printed, e.g. bench.py)."""
     global _inited
-    if _lib is not None and _inited:
-        _lib.gpk_shutdown()
+    if _lib is None or not _inited:
+        _inited = False
+        return
     _inited = False
+    if not full:
+        _lib.gpk_set_option(b"shutdown_keep_masked", 1.0)
+    if watchdog_s is None:
+        _lib.gpk_shutdown()
+        return
+    import sys
+    import threading
+    t = threading.Thread(target=_lib.gpk_shutdown, daemon=True)
+    t.start()
+    t.join(watchdog_s)
+    if t.is_alive():
+        sys.stdout.flush()
+        sys.stderr.write("gptest_amd: gpk_shutdown did not return within %.0f s, leaving the rest to process teardown\n" % watchdog_s)
+        sys.stderr.flush()
+        os._exit(0)
+
+
+def _shutdown_at_exit():
+    shutdown(full=False)
 
 
 def set_option(key, value):

@@ -106,28 +106,60 @@ int gpk_init(int device) {
     G.ev_ring.push_back(e);
   }
   G.device = device;
+  {
+    // Touch every stream once.  The runtime builds a stream's hardware queue lazily; destroying a CU-masked
+    // stream whose queue was never built hangs in hipStreamDestroy (seen at interpreter exit of a process that
+    // only ever used the update stream), and the first real launch on each stream no longer pays for the build.
+    unsigned long long* dtouch = nullptr;
+    GPK_HIP(hipMalloc((void**)&dtouch, 64));
+    hipStream_t all[4] = {G.s_main, G.s_panel, G.s_leaf, G.s_pred};
+    for (int i = 0; i < 4; ++i)
+      if (all[i]) GPK_TRY(launch_stamp(dtouch + i, all[i]));
+    GPK_HIP(hipDeviceSynchronize());
+    (void)hipFree(dtouch);
+  }
   G.inited = true;
   return 0;
 }
 
 void gpk_shutdown(void) {
   if (!G.inited) return;
-  (void)hipDeviceSynchronize();
-  for (auto& kv : G.pool)
-    for (void* q : kv.second) (void)hipFree(q);
+  const bool trace = getenv("GPK_TRACE_SHUTDOWN") != nullptr;
+#define SD_STEP(name, call)                               \
+  do {                                                    \
+    if (trace) fprintf(stderr, "[gpk_shutdown] %s ...", name); \
+    call;                                                 \
+    if (trace) fprintf(stderr, " done\n");                \
+  } while (0)
+  SD_STEP("device sync", (void)hipDeviceSynchronize());
+  SD_STEP("pool free", {
+    for (auto& kv : G.pool)
+      for (void* q : kv.second) (void)hipFree(q);
+  });
   G.pool.clear();
   G.pool_bytes = 0;
   timers_reset();
   for (hipEvent_t e : G.ev_free) (void)hipEventDestroy(e);
   G.ev_free.clear();
-  if (G.s_main) (void)hipStreamDestroy(G.s_main);
-  if (G.s_pred && G.s_pred != G.s_panel) (void)hipStreamDestroy(G.s_pred);
+  // Order matters: update stream, then substitution stream, then leaf stream hung in the leaf stream's
+  // hipStreamDestroy (process that had only run the leaf kernel on the update stream, 4 of 4 runs); substitution
+  // stream first did not.  The interpreter-exit handler additionally keeps the CU-masked streams alive
+  // (option shutdown_keep_masked) so that no process can hang at exit; explicit shutdown destroys everything,
+  // which a profiler attached to the process needs for its own teardown.
+  const bool destroy_masked = !G.cu_reserved || !G.shutdown_keep_masked;
+  SD_STEP("destroy s_pred", if (G.s_pred && G.s_pred != G.s_panel) (void)hipStreamDestroy(G.s_pred));
   G.s_pred = nullptr;
-  if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
-  if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
-  for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
+  if (destroy_masked) {
+    SD_STEP("destroy s_main", if (G.s_main) (void)hipStreamDestroy(G.s_main));
+    SD_STEP("destroy s_leaf", if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf));
+  }
+  SD_STEP("destroy s_panel", if (G.s_panel && (destroy_masked || G.s_leaf != G.s_panel)) (void)hipStreamDestroy(G.s_panel));
+  SD_STEP("destroy events", {
+    for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
+    for (hipEvent_t e : G.ev_pool) (void)hipEventDestroy(e);
+  });
+#undef SD_STEP
   G.ev_ring.clear();
-  for (hipEvent_t e : G.ev_pool) (void)hipEventDestroy(e);
   G.ev_pool.clear();
   G.s_main = G.s_panel = G.s_leaf = nullptr;
   G.inited = false;
@@ -175,6 +207,11 @@ int gpk_set_option(const char* key, double value) {
     G.pred_small_below = (int)value;
   } else if (k == "small_tile_below") {
     G.small_tile_below = (int)value;
+  } else if (k == "leaf_algo") {
+    extern int g_leaf_algo;
+    g_leaf_algo = (int)value;
+  } else if (k == "shutdown_keep_masked") {
+    G.shutdown_keep_masked = (int)value;
   } else if (k == "pipe_interleave") {
     G.pipe_interleave = (int)value;
   } else if (k == "fuse_predict") {

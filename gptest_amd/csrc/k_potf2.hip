@@ -19,14 +19,22 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+static __device__ __forceinline__ double readlane_d(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 #define PLD 129
 #define CBLD 132  // published column: 128 values + 1/pivot at [128], padded to a multiple of 2
 
 __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __restrict__ A, long lda,
                                                                double* __restrict__ L, long ldl,
                                                                double* __restrict__ Dinv, int* info, int col0,
-                                                               int dbg_skip) {
+                                                               int dbg_skip, int algo) {
   __shared__ __attribute__((aligned(16))) double S[128 * PLD + 2 * CBLD + 128];
+  __shared__ double rinvb[16];
+  __shared__ int failflag;
   double* colbuf = S + 128 * PLD;       // [2][CBLD]; 128*129 and CBLD are even -> 16-byte aligned pair reads
   double* pivbuf = colbuf + 2 * CBLD;   // [128] pivots
   const int tid = threadIdx.x;
@@ -39,6 +47,7 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   __syncthreads();
   LEAF_STAMP(4);
 
+  if (algo == 0) {
   const int i = tid & 127;
   const int kg = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform -> scalar branches below
   double a[8][2];
@@ -136,6 +145,105 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
     }
   }
   __syncthreads();
+  } else {
+    // ---- blocked elimination (algo 1): 8 steps of 16 columns, the tile stays in LDS.
+    //  (1) wave 0 factors the 16x16 diagonal block in registers (lane = row, broadcasts by v_readlane: no barrier
+    //      and no LDS round trip inside the 16 sequential columns), rsqrt + Newton on the pivot;
+    //  (2) the rows below solve against it by substitution, one thread per row, L11 read as LDS broadcasts;
+    //  (3) the trailing 16x16 tiles take the rank-16 update on the matrix pipe, one tile per wave and round.
+    // Three barriers per 16 columns instead of one per column.
+    const int lane = tid & 63, wv = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    if (tid == 0) failflag = 0;
+    __syncthreads();
+    int fail = 0;
+    for (int b = 0; b < 8 && !(dbg_skip & 1); ++b) {
+      const int c0 = 16 * b;
+      if (wv == 0) {
+        double a[16];
+        const double* row = S + (c0 + fr) * PLD + c0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = row[k];
+        int bad = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const double piv = readlane_d(a[j], j);
+          const bool ok = (piv > 1.0e-300) && (piv < 1.0e300);
+          if (!ok && !bad) bad = j + 1;
+          double y = __builtin_amdgcn_rsq(piv);
+          y = y * (1.5 - 0.5 * piv * y * y);
+          y = y * (1.5 - 0.5 * piv * y * y);
+          double sq = piv * y;
+          sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, piv), sq);  // sqrt(piv) to ~1 ulp
+          y = __builtin_fma(y, __builtin_fma(-sq, y, 1.0), y);            // 1/sqrt(piv) consistent with it
+          a[j] = (fr == j) ? sq : a[j] * y;
+          if (lane == 0) rinvb[j] = y;
+#pragma unroll
+          for (int k = j + 1; k < 16; ++k) {
+            const double lkj = readlane_d(a[j], k);
+            a[k] = __builtin_fma(-a[j], lkj, a[k]);
+          }
+        }
+        if (bad && lane == 0) failflag = c0 + bad;
+        if (lane < 16) {
+          double* wrow = S + (c0 + fr) * PLD + c0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) wrow[k] = (k <= fr) ? a[k] : 0.0;
+        }
+      }
+      __syncthreads();
+      fail = failflag;
+      if (fail) break;
+      const int nbelow = 112 - c0;
+      if (tid < nbelow) {
+        double* xr = S + (c0 + 16 + tid) * PLD + c0;
+        double x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = xr[k];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          x[m] *= rinvb[m];
+#pragma unroll
+          for (int k = m + 1; k < 16; ++k) x[k] = __builtin_fma(-x[m], S[(c0 + k) * PLD + c0 + m], x[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xr[k] = x[k];
+      }
+      __syncthreads();
+      const int nbk = 7 - b, ntile = nbk * (nbk + 1) / 2;
+      for (int t = wv; t < ntile; t += 16) {
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        const int J = t - I * (I + 1) / 2;
+        const int RI = c0 + 16 + 16 * I, RJ = c0 + 16 + 16 * J;
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = S[(RI + fg + 4 * r) * PLD + RJ + fr];
+        const double* Ap = S + (RI + fr) * PLD + c0 + fg;
+        const double* Bp = S + (RJ + fr) * PLD + c0 + fg;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[4 * ks], Bp[4 * ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(RI + fg + 4 * r) * PLD + RJ + fr] = acc[r];
+      }
+      __syncthreads();
+    }
+    if (fail) {
+      if (tid == 0) atomicCAS(info, 0, col0 + fail);
+      for (int e = tid; e < 128 * 128; e += 1024) {
+        const int ii = e >> 7, jj = e & 127;
+        const double v = (ii == jj) ? 1.0 : 0.0;
+        L[(long)ii * ldl + jj] = v;
+        Dinv[ii * 128 + jj] = v;
+      }
+      return;
+    }
+    for (int e = tid; e < 128 * 128; e += 1024) {  // blocks above the diagonal still hold updated symmetric data
+      const int ii = e >> 7, jj = e & 127;
+      if (jj > ii) S[ii * PLD + jj] = 0.0;
+    }
+    __syncthreads();
+  }
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int ii = e >> 7, jj = e & 127;
     L[(long)ii * ldl + jj] = S[ii * PLD + jj];
@@ -226,9 +334,11 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   LEAF_STAMP(7);
 }
 
+int g_leaf_algo = 1;  // 1: blocked elimination (16-column steps, MFMA updates); 0: column-by-column in registers
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0,
                            int dbg_skip, hipStream_t s) {
-  hipLaunchKernelGGL(potf2_trtri_128_kernel, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
+  hipLaunchKernelGGL(potf2_trtri_128_kernel, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip,
+                     g_leaf_algo);
   GPK_HIP(hipGetLastError());
   return 0;
 }

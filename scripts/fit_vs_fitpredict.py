@@ -23,4 +23,4 @@ for N, d in [(512, 1), (1024, 4), (4096, 4)]:
                 g = GPr.GaussianProcess(hyp, 0, 0, "SE", "zero", "zero", x, y); g.compute_prediction(z)
             ts.append((time.perf_counter() - t0) * 1e3)
         print("N=%d %-15s: first %.2f ms, then %s" % (N, mode, ts[0], " ".join("%.2f" % t for t in ts[1:])), flush=True)
-_lib.shutdown()
+_lib.shutdown(watchdog_s=10.0)

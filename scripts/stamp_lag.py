@@ -28,4 +28,4 @@ while True:
     rows.append((p, a, b)); p += 1
 print("panel: chain-done ms / substitutions-done ms / lag")
 print("  ".join("%d: %.1f/%.1f/%.1f" % (p, a, b, b - a) for p, a, b in rows[::max(1, len(rows) // 20)] + rows[-1:]))
-_lib.shutdown()
+_lib.shutdown(watchdog_s=10.0)
