@@ -12,8 +12,9 @@
 //     Square-root-free: column j and pivot j are final after step j, L = S*diag(1/sqrt(piv))
 //     is applied once at the end.
 //  2. In-place inverse of L in LDS (128 x 129 doubles, odd stride = conflict-free column
-//     walks) by recursive doubling, X21 = -X22*(L21*X11): block sizes 1..8 with scalar FMAs,
-//     16/32/64 with v_mfma_f64_16x16x4_f64 reading its fragments straight from the tile.
+//     walks): the 16x16 diagonal blocks by per-wave forward substitution, then recursive doubling
+//     X21 = -X22*(L21*X11) for block sizes 16/32/64 with v_mfma_f64_16x16x4_f64 reading its fragments
+//     straight from the tile.
 #include "gpk_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -25,6 +26,7 @@ static __device__ __forceinline__ double readlane_d(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
+#define LEAF_GRP 4  // readlane fence period in the diagonal-block factor (1: 51.6 us, 2: 49.3, 4: 49.4, 8: 50.1, none: 51.4)
 #define PLD 129
 #define CBLD 132  // published column: 128 values + 1/pivot at [128], padded to a multiple of 2
 
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
     int fail = 0;
     for (int b = 0; b < 8 && !(dbg_skip & 1); ++b) {
       const int c0 = 16 * b;
-      if (wv == 0) {
+      if (wv == 0 && !(dbg_skip & 64)) {
         double a[16];
         const double* row = S + (c0 + fr) * PLD + c0;
 #pragma unroll
@@ -178,10 +180,14 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
           y = __builtin_fma(y, __builtin_fma(-sq, y, 1.0), y);            // 1/sqrt(piv) consistent with it
           a[j] = (fr == j) ? sq : a[j] * y;
           if (lane == 0) rinvb[j] = y;
+          double aj = a[j];
 #pragma unroll
           for (int k = j + 1; k < 16; ++k) {
-            const double lkj = readlane_d(a[j], k);
-            a[k] = __builtin_fma(-a[j], lkj, a[k]);
+            const double lkj = readlane_d(aj, k);
+            a[k] = __builtin_fma(-aj, lkj, a[k]);
+            // the broadcasts land in SGPRs: left alone the scheduler hoists all of a column's (and the next
+            // column's) readlanes and spills scalar registers lane by lane; fence every GRP-th step
+            if (((k - j) % LEAF_GRP) == 0) asm volatile("" : "+v"(aj), "+v"(a[k]));
           }
         }
         if (bad && lane == 0) failflag = c0 + bad;
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
       fail = failflag;
       if (fail) break;
       const int nbelow = 112 - c0;
-      if (tid < nbelow) {
+      if (tid < nbelow && !(dbg_skip & 16)) {
         double* xr = S + (c0 + 16 + tid) * PLD + c0;
         double x[16];
 #pragma unroll
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
       }
       __syncthreads();
       const int nbk = 7 - b, ntile = nbk * (nbk + 1) / 2;
-      for (int t = wv; t < ntile; t += 16) {
+      for (int t = wv; t < ntile && !(dbg_skip & 32); t += 16) {
         int I = 0;
         while ((I + 1) * (I + 2) / 2 <= t) ++I;
         const int J = t - I * (I + 1) / 2;
@@ -253,34 +259,30 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   __syncthreads();
   LEAF_STAMP(5);
 
-  // ---- in-place inverse, block sizes 1, 2, 4, 8: scalar
-  const int nlev_scalar = (dbg_skip & 2) ? 0 : 4;
-  for (int lb = 0; lb < nlev_scalar; ++lb) {
-    const int b = 1 << lb;
-    const int nel = 64 * b;  // (64/b pairs) * b*b elements, <= 512
-    double t = 0.0;
-    int row = -1, col = 0;
-    if (tid < nel) {
-      const int pair = tid >> (2 * lb);
-      const int rem = tid & (b * b - 1);
-      const int ii = rem >> lb, c = rem & (b - 1);
-      const int r0 = 2 * b * pair;
-      row = r0 + b + ii;
-      col = r0 + c;
-      for (int k = c; k < b; ++k) t += S[row * PLD + r0 + k] * S[(r0 + k) * PLD + col];
+  // ---- inverses of the eight 16x16 diagonal blocks: one wave per block, lane = column of X = L11^-1, the column
+  // is built in registers by forward substitution (L11 rows arrive as LDS broadcasts; the diagonal already holds
+  // reciprocals) and then written over the block.  No barrier inside; replaces four levels of recursive doubling
+  // (block sizes 1..8, sixteen barriers) at the same cost.
+  if (!(dbg_skip & 2)) {
+    const int w16 = tid >> 6, c = tid & 63;
+    if (w16 < 8 && c < 16) {
+      const int c0 = 16 * w16;
+      double x[16];
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) {
+        const double* Li = S + (c0 + ii) * PLD + c0;
+        const double rii = Li[ii];
+        double sum = 0.0;
+#pragma unroll
+        for (int m = 0; m < ii; ++m) sum = __builtin_fma(Li[m], x[m], sum);  // x[m] = 0 for m < c
+        x[ii] = (ii == c) ? rii : ((ii > c) ? -sum * rii : 0.0);
+        asm volatile("" : "+v"(x[ii]) : : "memory");  // finish row ii before the reads of row ii+1 are issued: without
+                                                       // it all 120 broadcast reads are hoisted and the kernel spills
+      }
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii)
+        if (ii >= c) S[(c0 + ii) * PLD + c0 + c] = x[ii];
     }
-    __syncthreads();
-    if (row >= 0) S[row * PLD + col] = t;
-    __syncthreads();
-    if (row >= 0) {
-      const int rb = row & ~(2 * b - 1);
-      const int ii = row - rb - b;
-      double sum = 0.0;
-      for (int k = 0; k <= ii; ++k) sum += S[row * PLD + rb + b + k] * S[(rb + b + k) * PLD + col];
-      t = -sum;
-    }
-    __syncthreads();
-    if (row >= 0) S[row * PLD + col] = t;
     __syncthreads();
   }
   // ---- block sizes 16, 32, 64: MFMA.  b/4 output tiles of 16x16 per phase, one per wave.
