@@ -26,14 +26,88 @@ static __device__ __forceinline__ double readlane_d(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-#define LEAF_GRP 4  // readlane fence period in the diagonal-block factor (1: 51.6 us, 2: 49.3, 4: 49.4, 8: 50.1, none: 51.4)
 #define PLD 129
 #define CBLD 132  // published column: 128 values + 1/pivot at [128], padded to a multiple of 2
 
+// Factor of the 16x16 diagonal block at column c0 of the LDS tile, executed by ONE wave, rank-4 updates on the
+// matrix pipe.  The 16x16 block lives in ONE accumulator (C/D layout:
+// lane (r = lane & 15, k = lane >> 4), register q holds element (row k + 4q, col r)) and stays fully symmetric, so
+// register q of lane (r, k) IS the panel element (row r, column 4q + k) in MFMA operand layout: no data movement
+// between "take the next four columns" and "apply them".  Per four columns: gather the panel row-wise (4
+// ds_bpermute pairs), factor the four columns with readlane broadcasts (6 updates instead of 54), one
+// v_mfma_f64_16x16x4_f64 for the whole trailing block.  ~100 instructions per four columns against ~240 for the
+// lane-per-row version with 15 readlane broadcasts per column (measured 18.5 vs 19.4 us per leaf: the chain of
+// dependent fp64 operations per pivot, not the instruction count, is what is left).
+static __device__ __forceinline__ void leaf_diag_block_mfma(double* S, int c0, int lane, double* rinvb, int* failflag) {
+  const int r = lane & 15, k = lane >> 4;
+  d4 acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = k + 4 * q;  // only the lower triangle of the tile is read (LAPACK convention), mirrored
+    acc[q] = (row >= r) ? S[(c0 + row) * PLD + c0 + r] : S[(c0 + r) * PLD + c0 + row];
+  }
+  int bad = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int jb = 4 * q;
+    const double praw = acc[q];
+    double p[4], l[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p[c] = __shfl(praw, r + 16 * c, 64);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double piv = readlane_d(p[c], jb + c);
+      const bool ok = (piv > 1.0e-300) && (piv < 1.0e300);
+      if (!ok && !bad) bad = jb + c + 1;
+      double y = __builtin_amdgcn_rsq(piv);
+      const double hp = 0.5 * piv;
+      y = __builtin_fma(y, __builtin_fma(-hp * y, y, 0.5), y);
+      y = __builtin_fma(y, __builtin_fma(-hp * y, y, 0.5), y);
+      double sq = piv * y;
+      sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, piv), sq);
+      l[c] = (r == jb + c) ? sq : ((r > jb + c) ? p[c] * y : 0.0);
+      if (lane == 0) rinvb[jb + c] = y;
+#pragma unroll
+      for (int c2 = c + 1; c2 < 4; ++c2) {
+        const double lkj = readlane_d(l[c], jb + c2);
+        p[c2] = __builtin_fma(-l[c], lkj, p[c2]);
+      }
+    }
+    if (lane < 16) {
+      double* wrow = S + (c0 + r) * PLD + c0 + jb;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wrow[c] = l[c];
+    }
+    if (q < 3) {
+      const double pk = (k == 0) ? l[0] : (k == 1) ? l[1] : (k == 2) ? l[2] : l[3];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pk, pk, acc, 0, 0, 0);
+    }
+  }
+  if (bad && lane == 0) *failflag = c0 + bad;
+}
+// rank-16 update of trailing tile t (triangular numbering, tile 0 = the next diagonal block) on the matrix pipe
+static __device__ __forceinline__ void leaf_update_tile(double* S, int c0, int t, int fr, int fg) {
+  int I = 0;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int J = t - I * (I + 1) / 2;
+  const int RI = c0 + 16 + 16 * I, RJ = c0 + 16 + 16 * J;
+  d4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = S[(RI + fg + 4 * r) * PLD + RJ + fr];
+  const double* Ap = S + (RI + fr) * PLD + c0 + fg;
+  const double* Bp = S + (RJ + fr) * PLD + c0 + fg;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[4 * ks], Bp[4 * ks], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[(RI + fg + 4 * r) * PLD + RJ + fr] = acc[r];
+}
+
+template <int ALGO>  // 0: column-by-column elimination in registers; 1: blocked elimination (default)
 __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __restrict__ A, long lda,
                                                                double* __restrict__ L, long ldl,
                                                                double* __restrict__ Dinv, int* info, int col0,
-                                                               int dbg_skip, int algo) {
+                                                               int dbg_skip) {
+  constexpr int algo = ALGO;
   __shared__ __attribute__((aligned(16))) double S[128 * PLD + 2 * CBLD + 128];
   __shared__ double rinvb[16];
   __shared__ int failflag;
@@ -149,57 +223,23 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   __syncthreads();
   } else {
     // ---- blocked elimination (algo 1): 8 steps of 16 columns, the tile stays in LDS.
-    //  (1) wave 0 factors the 16x16 diagonal block in registers (lane = row, broadcasts by v_readlane: no barrier
-    //      and no LDS round trip inside the 16 sequential columns), rsqrt + Newton on the pivot;
+    //  (1) wave 0 factors the 16x16 diagonal block in one MFMA accumulator (leaf_diag_block_mfma: no barrier and no
+    //      LDS round trip inside the 16 sequential columns), rsqrt + Newton on the pivot;
     //  (2) the rows below solve against it by substitution, one thread per row, L11 read as LDS broadcasts;
-    //  (3) the trailing 16x16 tiles take the rank-16 update on the matrix pipe, one tile per wave and round.
-    // Three barriers per 16 columns instead of one per column.
+    //  (3) the trailing 16x16 tiles take the rank-16 update on the matrix pipe, one tile per wave and round, while
+    //      wave 0, after updating the next diagonal tile, already factors it (look-ahead).
+    // Two barriers per 16 columns instead of one per column.
     const int lane = tid & 63, wv = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     if (tid == 0) failflag = 0;
     __syncthreads();
     int fail = 0;
-    for (int b = 0; b < 8 && !(dbg_skip & 1); ++b) {
+    const bool run = !(dbg_skip & 1);
+    if (run && wv == 0 && !(dbg_skip & 64)) leaf_diag_block_mfma(S, 0, lane, rinvb, &failflag);
+    __syncthreads();
+    fail = failflag;
+    for (int b = 0; b < 8 && run && !fail; ++b) {
       const int c0 = 16 * b;
-      if (wv == 0 && !(dbg_skip & 64)) {
-        double a[16];
-        const double* row = S + (c0 + fr) * PLD + c0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = row[k];
-        int bad = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const double piv = readlane_d(a[j], j);
-          const bool ok = (piv > 1.0e-300) && (piv < 1.0e300);
-          if (!ok && !bad) bad = j + 1;
-          double y = __builtin_amdgcn_rsq(piv);
-          y = y * (1.5 - 0.5 * piv * y * y);
-          y = y * (1.5 - 0.5 * piv * y * y);
-          double sq = piv * y;
-          sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, piv), sq);  // sqrt(piv) to ~1 ulp
-          y = __builtin_fma(y, __builtin_fma(-sq, y, 1.0), y);            // 1/sqrt(piv) consistent with it
-          a[j] = (fr == j) ? sq : a[j] * y;
-          if (lane == 0) rinvb[j] = y;
-          double aj = a[j];
-#pragma unroll
-          for (int k = j + 1; k < 16; ++k) {
-            const double lkj = readlane_d(aj, k);
-            a[k] = __builtin_fma(-aj, lkj, a[k]);
-            // the broadcasts land in SGPRs: left alone the scheduler hoists all of a column's (and the next
-            // column's) readlanes and spills scalar registers lane by lane; fence every GRP-th step
-            if (((k - j) % LEAF_GRP) == 0) asm volatile("" : "+v"(aj), "+v"(a[k]));
-          }
-        }
-        if (bad && lane == 0) failflag = c0 + bad;
-        if (lane < 16) {
-          double* wrow = S + (c0 + fr) * PLD + c0;
-#pragma unroll
-          for (int k = 0; k < 16; ++k) wrow[k] = (k <= fr) ? a[k] : 0.0;
-        }
-      }
-      __syncthreads();
-      fail = failflag;
-      if (fail) break;
       const int nbelow = 112 - c0;
       if (tid < nbelow && !(dbg_skip & 16)) {
         double* xr = S + (c0 + 16 + tid) * PLD + c0;
@@ -216,23 +256,18 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
         for (int k = 0; k < 16; ++k) xr[k] = x[k];
       }
       __syncthreads();
+      if (b == 7) break;
+      // look-ahead: wave 0 updates the next diagonal tile and factors it at once (2.1 us) while the other
+      // fifteen waves apply the rest of this step's update (<= 27 tiles)
       const int nbk = 7 - b, ntile = nbk * (nbk + 1) / 2;
-      for (int t = wv; t < ntile && !(dbg_skip & 32); t += 16) {
-        int I = 0;
-        while ((I + 1) * (I + 2) / 2 <= t) ++I;
-        const int J = t - I * (I + 1) / 2;
-        const int RI = c0 + 16 + 16 * I, RJ = c0 + 16 + 16 * J;
-        d4 acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = S[(RI + fg + 4 * r) * PLD + RJ + fr];
-        const double* Ap = S + (RI + fr) * PLD + c0 + fg;
-        const double* Bp = S + (RJ + fr) * PLD + c0 + fg;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[4 * ks], Bp[4 * ks], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[(RI + fg + 4 * r) * PLD + RJ + fr] = acc[r];
+      if (wv == 0) {
+        if (!(dbg_skip & 32)) leaf_update_tile(S, c0, 0, fr, fg);
+        if (!(dbg_skip & 64)) leaf_diag_block_mfma(S, c0 + 16, lane, rinvb, &failflag);
+      } else {
+        for (int t = wv; t < ntile && !(dbg_skip & 32); t += 15) leaf_update_tile(S, c0, t, fr, fg);
       }
       __syncthreads();
+      fail = failflag;
     }
     if (fail) {
       if (tid == 0) atomicCAS(info, 0, col0 + fail);
@@ -339,8 +374,10 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
 int g_leaf_algo = 1;  // 1: blocked elimination (16-column steps, MFMA updates); 0: column-by-column in registers
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0,
                            int dbg_skip, hipStream_t s) {
-  hipLaunchKernelGGL(potf2_trtri_128_kernel, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip,
-                     g_leaf_algo);
+  if (g_leaf_algo == 0)
+    hipLaunchKernelGGL(potf2_trtri_128_kernel<0>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
+  else
+    hipLaunchKernelGGL(potf2_trtri_128_kernel<1>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
   GPK_HIP(hipGetLastError());
   return 0;
 }
