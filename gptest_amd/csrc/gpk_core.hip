@@ -386,9 +386,13 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
     GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
     const int r1 = r0 + wn;
     if (m->Npad - r1 > 0) {
-      timer_begin("trailing", sm, (double)(m->Npad - r1) * (m->Npad - r1) * m->pw[p]);
+      // "trailing" = the launches of the 8-wave kernel (the roofline object of bench.py); the latency-bound
+      // tail that panel_update routes to the 64x64-tile kernel is timed under its own name
+      const long nt = (m->Npad - r1) / 128;
+      const char* tname = (nt * (nt + 1) / 2 < G.small_tile_below) ? "trailing_small" : "trailing";
+      timer_begin(tname, sm, (double)(m->Npad - r1) * (m->Npad - r1) * m->pw[p]);
       GPK_TRY(panel_update(m, p, r1, r1, m->Npad - r1, 1, sm));
-      timer_end("trailing", sm);
+      timer_end(tname, sm);
     }
     GPK_HIP(hipEventRecord(ev_trail[p], sm));
   }

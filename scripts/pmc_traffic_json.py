@@ -1,0 +1,62 @@
+"""Per-launch HBM traffic of the trailing-update kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
+`bench.py --steps 2 --warmup 1`: the gemm_nt8_kernel launches of the LAST posterior that ran on the update stream
+(= the launches bench.py brackets with HIP events).  Units and the gfx950 correction follow MI355X_MICROARCH.md
+(counters in KiB; FETCH_SIZE doubled)."""
+import csv, glob, json, sys
+
+def load(d, counter):
+    f = sorted(glob.glob(d + "/*/*counter_collection.csv"))[-1]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    return rows
+
+def wgs(r):
+    g = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+    w = int(r["Workgroup_Size"]) if "Workgroup_Size" in r else int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+    return g // w
+
+def trailing(rows):
+    qkey = "Queue_Id"
+    kb = [r for r in rows if "se_build" in r["Kernel_Name"]]
+    main_q = max(kb, key=wgs)[qkey]
+    g = [r for r in rows if "gemm_nt8" in r["Kernel_Name"] and r[qkey] == main_q]
+    per_step = len(g) // 3            # warmup 1 + steps 2
+    return g[-per_step:]
+
+fe = trailing(load(sys.argv[1], "FETCH_SIZE"))
+wr = trailing(load(sys.argv[2], "WRITE_SIZE"))
+assert len(fe) == len(wr) and len(fe) > 0, (len(fe), len(wr))
+fetch_raw = sum(float(r["Counter_Value"]) for r in fe)
+write_raw = sum(float(r["Counter_Value"]) for r in wr)
+n = len(fe)
+# algorithmic bytes: every lower 128x128 tile of C read + written once (16 B per element) + the panel read once;
+# exact algorithmic figures come from the panel schedule (same rule as gpk_core.hip model_create / potrf_device)
+N = 16384
+rem = N; c0 = 0; sched = []
+while c0 < N:
+    rem = N - c0
+    w = 512 if rem > 8192 + 512 else (128 if rem <= 2048 else 256)
+    sched.append((c0, w)); c0 += w
+alg_list = []
+for p, (c0, w) in enumerate(sched):
+    wn = sched[p + 1][1] if p + 1 < len(sched) else 0
+    m = N - c0 - w - wn
+    if m <= 0: continue
+    nt = m // 128
+    if nt * (nt + 1) // 2 < 256: continue          # small launches use the 64x64-tile kernel (small_tile_below)
+    alg_list.append((16.0 * 128 * 128 * nt * (nt + 1) / 2 + 8.0 * m * w, float(m) * m * w))
+out = {
+    "kernel": "gemm_nt8_kernel (trailing-update launches of one factorisation on the update stream, N=16384)",
+    "launches": n,
+    "launches_expected_from_schedule": len(alg_list),
+    "fetch_size_kb_raw": fetch_raw,
+    "write_size_kb_raw": write_raw,
+    "fetch_bytes_corrected_x2": fetch_raw * 1024.0 * 2.0,
+    "write_bytes": write_raw * 1024.0,
+    "hbm_bytes_per_launch": (fetch_raw * 1024.0 * 2.0 + write_raw * 1024.0) / n,
+    "algorithmic_bytes_per_launch": sum(a for a, _ in alg_list) / max(1, len(alg_list)),
+    "algorithmic_flops_per_launch": sum(f for _, f in alg_list) / max(1, len(alg_list)),
+    "note": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --steps 2 --warmup 1`; counters in KiB; "
+            "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); algorithmic = 16 B per element of the lower C tiles (read + written once) "
+            "+ 8*m*w (panel read once)",
+}
+print(json.dumps(out, indent=1))
