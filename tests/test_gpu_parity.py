@@ -562,3 +562,34 @@ def test_gppref_predict_latent_reproduces_mode_at_training_points(gpk):
     assert np.max(np.abs(mean - f.ravel())) < 1e-3 * np.abs(f).max()
     with pytest.raises(RuntimeError):
         GPpref.PreferenceGaussianProcess(x, uvi, y).predict_latent(x)
+
+
+# ----------------------------------------------------------------------------- retained alternative code paths
+@pytest.mark.parametrize("opts", [
+    {"leaf_algo": 0},                                    # column-by-column leaf elimination
+    {"small_tile_below": 0, "pred_small_below": 96},     # 128x128 tiles for every panel update
+    {"pipe_interleave": 1},                              # substitutions submitted right after their panel
+    {"fuse_predict": 0},                                 # prediction after the factorisation
+    {"lookahead": 0},                                    # one stream, no look-ahead
+    {"nb": 128},                                         # uniform panels instead of the 512/256/128 schedule
+])
+def test_option_paths_keep_parity(gpk, opts):
+    """Every switch that selects another kernel or schedule must leave the posterior within the parity bar."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+    defaults = {"nb": 256, "leaf_algo": 1, "small_tile_below": 256, "pred_small_below": 300, "pipe_interleave": 0,
+                "fuse_predict": 1, "lookahead": 1, "nb_auto": 1}   # "nb" switches nb_auto off: nb_auto is restored last
+    x, y, z, lh = orc.synthetic_problem(1500, 3, M=130, seed=21)
+    nl, fz, cov = orc.posterior_efficient(lh, x, y, z)
+    try:
+        for k, v in opts.items():
+            gpk.set_option(k, v)
+        gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", x, y)
+        mean, var = gp.compute_prediction(z)
+        nlml = gp.compute_likelihood(lh).flat[0]
+    finally:
+        for k, v in defaults.items():
+            gpk.set_option(k, v)
+    assert abs(nlml - nl) <= RTOL * abs(nl)
+    np.testing.assert_allclose(mean, fz, rtol=RTOL, atol=RTOL * np.abs(fz).max())
+    np.testing.assert_allclose(var, cov, rtol=RTOL, atol=RTOL * np.abs(cov).max())
