@@ -212,6 +212,10 @@ int gpk_set_option(const char* key, double value) {
     g_leaf_algo = (int)value;
   } else if (k == "shutdown_keep_masked") {
     G.shutdown_keep_masked = (int)value;
+  } else if (k == "test_gemm_k1") {
+    G.test_gemm_k1 = (int)value;
+  } else if (k == "pair_update") {
+    G.pair_update = (int)value;
   } else if (k == "pipe_interleave") {
     G.pipe_interleave = (int)value;
   } else if (k == "fuse_predict") {
@@ -747,7 +751,24 @@ int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, 
     GemmNT g{};
     g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
     g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
+    double *dA2 = nullptr, *dB2 = nullptr;
+    const int k1 = G.test_gemm_k1;
+    if (k1 > 0 && k1 < k) {
+      // same product with the K range split over two separately stored operands (the paired trailing update)
+      // second segment stored separately but with the same leading dimension k (columns [0, k2) used)
+      const int k2 = k - k1;
+      if (dev_alloc_t(&dA2, (size_t)m * k) || dev_alloc_t(&dB2, (size_t)n * k)) { rc = -2; break; }
+      if (hipMemcpy2DAsync(dA2, (size_t)k * 8, dA + k1, (size_t)k * 8, (size_t)k2 * 8, m, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipMemcpy2DAsync(dB2, (size_t)k * 8, dB + k1, (size_t)k * 8, (size_t)k2 * 8, n, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        rc = gpk_set_err(-2, "segment copy failed");
+        break;
+      }
+      g.A2 = dA2; g.lda2 = k; g.B2 = dB2; g.ldb2 = k; g.k1 = k1;
+    }
     rc = launch_gemm_nt(g, tile == 128, s);
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = gpk_set_err(-2, "test_gemm: %s", hipGetErrorString(hipGetLastError()));
+    if (dA2) dev_free(dA2, (size_t)m * k * 8);
+    if (dB2) dev_free(dB2, (size_t)n * k * 8);
     if (rc) break;
     if (hipMemcpyAsync(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
     if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "test_gemm: %s", hipGetErrorString(hipGetLastError())); break; }

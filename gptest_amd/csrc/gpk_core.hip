@@ -340,6 +340,97 @@ int ensure_ev_pool(int n) {
 // leaf/panel kernels leave the critical path.
 static int potrf_distributed(gpk_model* m);
 
+// C[r0g:, r0g:] (lower) -= [Lp Lq][Lp Lq]^T for two CONSECUTIVE panels p, q = p+1 in ONE pass over C (K = w_p + w_q):
+// half the C traffic and accumulator hand-overs per flop of two separate updates.  Falls back to two launches when
+// the update is small enough for the 64x64-tile kernel (which has no second K segment).
+static int pair_update(gpk_model* m, int p, int r0g, hipStream_t s) {
+  const int np_ = m->Npad, rows = np_ - r0g;
+  if (rows <= 0) return 0;
+  const long nt = rows / 128;
+  if (nt * (nt + 1) / 2 < G.small_tile_below || m->pw[p] != m->pw[p + 1]) {  // the kernel wants equal panel widths
+    GPK_TRY(panel_update(m, p, r0g, r0g, rows, 1, s));
+    return panel_update(m, p + 1, r0g, r0g, rows, 1, s);
+  }
+  const int c0 = m->pc0[p], w = m->pw[p], c1 = m->pc0[p + 1], w1 = m->pw[p + 1];
+  GemmNT g{};
+  g.A = m->Lpanel(p) + (long)(r0g - c0) * w; g.lda = w;
+  g.B = g.A; g.ldb = w;
+  g.A2 = m->Lpanel(p + 1) + (long)(r0g - c1) * w1; g.lda2 = w1;
+  g.B2 = g.A2; g.ldb2 = w1;
+  g.k1 = w; g.k = w + w1;
+  g.C = m->dK + (long)r0g * np_ + r0g; g.ldc = np_;
+  g.m = rows; g.n = rows; g.sub = 1; g.lower = 1;
+  return launch_gemm_auto(g, s);
+}
+
+// Look-ahead factorisation with PAIRED trailing updates (single GPU).  Panels (p, p+1), p even:
+//   s_panel:  LA(p -> block column p+1) . factor(p+1) . LA(p+1 -> block column p+2) . factor(p+2) ...
+//   s_main :  near(p -> block column p+2) . farA(p, p+1 -> block column p+3) . farB(p, p+1 -> everything right of it)
+// farB carries almost all the flops and runs with K = w_p + w_{p+1}; near/farA are the narrow pieces the panel chain
+// needs early, so the chain runs up to two panels ahead of the bulk update and s_main never waits for a panel.
+//   LA(p)   waits farA(p-2, p-1)   (block column p+1 complete w.r.t. all earlier panels)
+//   LA(p+1) waits near(p)          (queued behind farB(p-2, p-1) on s_main, which covers block column p+2)
+static int potrf_device_paired(gpk_model* m, const std::function<int(int)>* after_panel) {
+  hipStream_t sm = G.s_main, sp = G.s_panel;
+  const int nP = m->nP, np_ = m->Npad;
+  GPK_TRY(ensure_ev_pool(3 * nP + 6));
+  g_potrf_lookahead_used = 1;
+  hipEvent_t* ev_panel = G.ev_pool.data();
+  hipEvent_t* ev_near = G.ev_pool.data() + nP;
+  hipEvent_t* ev_farA = G.ev_pool.data() + 2 * nP + 6;
+  hipEvent_t ev_start = G.ev_pool[2 * nP];
+  auto c = [&](int q) { return q < nP ? m->pc0[q] : np_; };
+  auto wd = [&](int q) { return q < nP ? m->pw[q] : 0; };
+  GPK_HIP(hipEventRecord(ev_start, sm));
+  GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
+  GPK_TRY(factor_panel(m, 0, sp));
+  GPK_HIP(hipEventRecord(ev_panel[0], sp));
+  if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + 0, sp));
+  if (after_panel) GPK_TRY((*after_panel)(0));
+  for (int p = 0; p < nP; p += 2) {
+    const bool hasB = p + 1 < nP;
+    // ---- panel chain: A = p
+    if (hasB) {
+      if (p >= 2) GPK_HIP(hipStreamWaitEvent(sp, ev_farA[p - 2], 0));
+      GPK_TRY(panel_update(m, p, c(p + 1), c(p + 1), wd(p + 1), 0, sp));
+      GPK_TRY(factor_panel(m, p + 1, sp));
+      GPK_HIP(hipEventRecord(ev_panel[p + 1], sp));
+      if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p + 1, sp));
+      if (after_panel) GPK_TRY((*after_panel)(p + 1));
+    }
+    // ---- update stream: near(p -> block column p+2)
+    GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
+    if (p + 2 < nP) GPK_TRY(panel_update(m, p, c(p + 2), c(p + 2), wd(p + 2), 0, sm));
+    GPK_HIP(hipEventRecord(ev_near[p], sm));
+    // ---- panel chain: B = p+1
+    if (p + 2 < nP) {
+      GPK_HIP(hipStreamWaitEvent(sp, ev_near[p], 0));
+      GPK_TRY(panel_update(m, p + 1, c(p + 2), c(p + 2), wd(p + 2), 0, sp));
+      GPK_TRY(factor_panel(m, p + 2, sp));
+      GPK_HIP(hipEventRecord(ev_panel[p + 2], sp));
+      if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p + 2, sp));
+      if (after_panel) GPK_TRY((*after_panel)(p + 2));
+    }
+    // ---- update stream: farA (block column p+3, from both panels), farB (the rest, one pass)
+    if (hasB) GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p + 1], 0));
+    if (p + 3 < nP) {
+      GPK_TRY(panel_update(m, p, c(p + 3), c(p + 3), wd(p + 3), 0, sm));
+      GPK_TRY(panel_update(m, p + 1, c(p + 3), c(p + 3), wd(p + 3), 0, sm));
+    }
+    GPK_HIP(hipEventRecord(ev_farA[p], sm));
+    if (p + 4 < nP) {
+      const int r4 = c(p + 4);
+      const long nt = (np_ - r4) / 128;
+      const char* tname = (nt * (nt + 1) / 2 < G.small_tile_below) ? "trailing_small" : "trailing";
+      timer_begin(tname, sm, (double)(np_ - r4) * (np_ - r4) * (wd(p) + wd(p + 1)));
+      GPK_TRY(pair_update(m, p, r4, sm));
+      timer_end(tname, sm);
+    }
+  }
+  GPK_HIP(hipStreamWaitEvent(sm, ev_panel[nP - 1], 0));
+  return 0;
+}
+
 int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   hipStream_t sm = G.s_main, sp = G.s_panel;
   GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
@@ -358,7 +449,12 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
     }
     return 0;
   }
-  GPK_TRY(ensure_ev_pool(2 * nP + 6));
+  // paired updates let the panel chain run two panels ahead of the bulk update: +3-9 % where the chain is the bound
+  // (N = 4096: 309 -> 318 posteriors/s, N = 8192: +2 %).  From N = 16384 on they lose: the K-doubled far update does
+  // run faster (50 vs 44.5 TFLOP/s) but the three narrow updates per pair it needs (16 % of the flops) cost more
+  // than that (N = 16384: 38.1-38.5 vs 36.9-37.05 ms, N = 32768: 241.8 vs 231.9).  1: only up to 8192, 2: always.
+  if (nP >= 6 && (G.pair_update == 2 || (G.pair_update == 1 && m->Npad <= 8192))) return potrf_device_paired(m, after_panel);
+  GPK_TRY(ensure_ev_pool(3 * nP + 6));
   g_potrf_lookahead_used = 1;
   hipEvent_t* ev_panel = G.ev_pool.data();        // panel p factored (recorded on s_panel)
   hipEvent_t* ev_trail = G.ev_pool.data() + nP;   // rest-update of step p done (recorded on s_main)
@@ -440,7 +536,7 @@ static int potrf_distributed(gpk_model* m) {
     }
     return 0;
   }
-  GPK_TRY(ensure_ev_pool(2 * nP + 6));
+  GPK_TRY(ensure_ev_pool(3 * nP + 6));
   hipEvent_t* ev_panel = G.ev_pool.data();       // panel p available on this rank (recorded on s_panel)
   hipEvent_t* ev_trail = G.ev_pool.data() + nP;  // rest-update of step p done (recorded on s_main)
   hipEvent_t ev_start = G.ev_pool[2 * nP];
@@ -529,7 +625,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   const bool fuse = fp && G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3;
   if (G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3 && (fuse || m->has_y)) {
     // s_pred may start once K is built (Kzx only needs X, the y substitution only panels and y)
-    GPK_TRY(ensure_ev_pool(2 * m->nP + 6));
+    GPK_TRY(ensure_ev_pool(3 * m->nP + 6));
     ev_kb = G.ev_pool[2 * m->nP + 2];
     GPK_HIP(hipEventRecord(ev_kb, s));
   }
@@ -690,7 +786,7 @@ int rows_forward_solve(gpk_model* m, int Mpad, double* dR, double* dV) {
   } else {
     // one panel of look-ahead, as in the factorisation: the latency-bound diagonal solves of panel p+1 run on
     // s_panel while the wide update of panel p runs on s_main.
-    GPK_TRY(ensure_ev_pool(2 * nP + 6));
+    GPK_TRY(ensure_ev_pool(3 * nP + 6));
     hipEvent_t* ev_diag = G.ev_pool.data();
     hipEvent_t* ev_upd = G.ev_pool.data() + nP;
     hipEvent_t ev_start = G.ev_pool[2 * nP];

@@ -43,6 +43,11 @@ struct GemmNT {
   long row_g0;   // global row index of C row 0
   long brow_g0;  // global row index of B row 0 (B tile row = gcol(tj) - brow_g0 when cyc_P > 0 or lower)
   int xcd_sq;    // 8-wave kernel: XCD-aware 8x8-tile square order (single GPU)
+  // optional second K segment (8-wave kernel only): columns [k1, k) of the operands come from A2/B2 (two panels
+  // stored separately applied as ONE update: C -= [A A2][B B2]^T).  k1 == 0: single segment.
+  const double* A2; long lda2;
+  const double* B2; long ldb2;
+  int k1;
 };
 // tile128 = true: 128x128 block tile (4x4 MFMA tiles per wave); false: 64x64 (2x2 per wave).
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s);

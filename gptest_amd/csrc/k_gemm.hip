@@ -150,6 +150,7 @@ int g_gemm_variant = 8;  // 8: 8-wave 128x128 kernel (default); 4: the 4-wave ke
 // sub mode: the accumulators START as C (loaded while the first K-slab is in flight) and A is
 // negated on its way into LDS, so the MFMA chain itself yields C - A*B^T and the epilogue is
 // store-only (no load -> subtract -> store dependency at the end of every tile).
+template <bool TWOSEG>  // TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update)
 __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   constexpr int BT = 128;
   __shared__ double lds[2 * 2 * BT * LDS_LD];
@@ -226,11 +227,29 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   }
 
   d2 ra[2], rb[2];
+  const int nk1 = TWOSEG ? g.k1 / BK : 0;  // slabs of the first K segment
+  const double* Ag2 = TWOSEG ? g.A2 + (long)ti * BT * g.lda2 : Ag;
+  const double* Bg2 = TWOSEG ? g.B2 + brow0 * g.ldb2 : Bg;
   auto gload = [&](int kt) {
+    if (TWOSEG) {
+      // wave-uniform segment select: slabs [0, nk1) from (A, B), the rest from (A2, B2).  Both segments have the
+      // same leading dimensions (host check), so only the scalar base and slab index differ from the plain path:
+      // a per-slab select of the leading dimension cost 5 % of the kernel (per-thread 64-bit offset arithmetic).
+      const bool first = kt < nk1;
+      const double* Ap = first ? Ag : Ag2;
+      const double* Bp = first ? Bg : Bg2;
+      const int kk = (first ? kt : kt - nk1) * BK + lchk;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      ra[p] = *reinterpret_cast<const d2*>(Ag + (long)(p * 64 + lrow) * g.lda + kt * BK + lchk);
-      rb[p] = *reinterpret_cast<const d2*>(Bg + (long)(p * 64 + lrow) * g.ldb + kt * BK + lchk);
+      for (int p = 0; p < 2; ++p) {
+        ra[p] = *reinterpret_cast<const d2*>(Ap + (long)(p * 64 + lrow) * g.lda + kk);
+        rb[p] = *reinterpret_cast<const d2*>(Bp + (long)(p * 64 + lrow) * g.ldb + kk);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        ra[p] = *reinterpret_cast<const d2*>(Ag + (long)(p * 64 + lrow) * g.lda + kt * BK + lchk);
+        rb[p] = *reinterpret_cast<const d2*>(Bg + (long)(p * 64 + lrow) * g.ldb + kt * BK + lchk);
+      }
     }
   };
   const double sgn = g.sub ? -1.0 : 1.0;
@@ -287,6 +306,12 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
     return gpk_set_err(-1, "gemm_nt: bad shape m=%d n=%d k=%d (tile %d)", g.m, g.n, g.k, BT);
   if ((g.lda & 1) || (g.ldb & 1) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15))
     return gpk_set_err(-1, "gemm_nt: operands must be 16-byte aligned with even leading dimensions");
+  if (g.k1 > 0) {
+    if (!tile128 || g_gemm_variant != 8 || g.cyc_P != 0)
+      return gpk_set_err(-1, "gemm_nt: a second K segment needs the 8-wave single-GPU kernel");
+    if (g.k1 % BK || g.k1 >= g.k || !g.A2 || !g.B2 || g.lda2 != g.lda || g.ldb2 != g.ldb || ((uintptr_t)g.A2 & 15) || ((uintptr_t)g.B2 & 15))
+      return gpk_set_err(-1, "gemm_nt: bad second K segment (k1=%d k=%d)", g.k1, g.k);
+  }
   const int ntm = g.m / BT, ntn = g.n / BT;
   long nblk;
   if (g.lower && g.cyc_P == 0) {
@@ -301,7 +326,8 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
       const long nsq = g.lower ? SM * (SM + 1) / 2 : SM * SN;
       nblk = ((nsq + 7) / 8) * 8 * 64;
     }
-    hipLaunchKernelGGL(gemm_nt8_kernel, dim3((unsigned)nblk), dim3(512), 0, s, g);
+    if (g.k1 > 0) hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL(gemm_nt8_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, s, g);
   }
   else if (tile128)
     hipLaunchKernelGGL(gemm_nt_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, g);

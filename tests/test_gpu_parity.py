@@ -62,6 +62,26 @@ def test_tile_sizes_round_identically(gpk, sub):
     np.testing.assert_array_equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("m,n,k,k1,lower", [(256, 384, 256, 128, 0), (512, 512, 384, 256, 1), (2048, 2048, 768, 512, 1)])
+def test_two_segment_k_is_bitwise_one_update(gpk, m, n, k, k1, lower):
+    """The paired trailing update reads its K range from two separately stored panels; the result must be the
+    very bits of the single-operand product (same slab order)."""
+    rng = np.random.RandomState(k + k1)
+    A = rng.randn(m, k)
+    B = A.copy() if lower else rng.randn(n, k)
+    C0 = rng.randn(m, n)
+    out = []
+    for split in (0, k1):
+        gpk.set_option("test_gemm_k1", split)
+        C = C0.copy()
+        try:
+            assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, lower, 128) == 0, gpk.last_error()
+        finally:
+            gpk.set_option("test_gemm_k1", 0)
+        out.append(C)
+    np.testing.assert_array_equal(out[0], out[1])
+
+
 def test_mfma_fragment_layout_identity(gpk):
     """The f64 MFMA C/D map differs from every other dtype (guide section 3): A = I, asymmetric B."""
     A = np.zeros((128, 16))
@@ -572,13 +592,15 @@ def test_gppref_predict_latent_reproduces_mode_at_training_points(gpk):
     {"fuse_predict": 0},                                 # prediction after the factorisation
     {"lookahead": 0},                                    # one stream, no look-ahead
     {"nb": 128},                                         # uniform panels instead of the 512/256/128 schedule
+    {"pair_update": 0},                                  # one panel per trailing update
+    {"pair_update": 2, "nb": 128},                       # paired updates on more than five panels
 ])
 def test_option_paths_keep_parity(gpk, opts):
     """Every switch that selects another kernel or schedule must leave the posterior within the parity bar."""
     from gptest_amd import GPr
     from oracle import gpr_oracle as orc
     defaults = {"nb": 256, "leaf_algo": 1, "small_tile_below": 256, "pred_small_below": 300, "pipe_interleave": 0,
-                "fuse_predict": 1, "lookahead": 1, "nb_auto": 1}   # "nb" switches nb_auto off: nb_auto is restored last
+                "fuse_predict": 1, "lookahead": 1, "pair_update": 1, "nb_auto": 1}   # "nb" switches nb_auto off: nb_auto is restored last
     x, y, z, lh = orc.synthetic_problem(1500, 3, M=130, seed=21)
     nl, fz, cov = orc.posterior_efficient(lh, x, y, z)
     try:
