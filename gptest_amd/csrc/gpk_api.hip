@@ -138,6 +138,9 @@ void gpk_shutdown(void) {
   });
   G.pool.clear();
   G.pool_bytes = 0;
+  if (G.dstamps) (void)hipFree(G.dstamps);
+  G.dstamps = nullptr;
+  G.hstamps.clear();
   timers_reset();
   for (hipEvent_t e : G.ev_free) (void)hipEventDestroy(e);
   G.ev_free.clear();
