@@ -112,6 +112,7 @@ int comm_allgather(const double* send, double* recv, size_t count, hipStream_t s
 // right-hand sides, results all-gathered); dmv_out receives mean[0:M] at [0] and var[0:M] at [Mtot]
 int predict_sharded(gpk_model* m, const double* dZ, int M, double* h_mean, double* h_var);
 int nlml_grad_device(gpk_model* m, double* h_grad);
+int potrf_forward(gpk_model* m, double* v);                   // dK -> dL, v <- L^-1 v (pipelined)
 int rows_forward_solve(gpk_model* m, int Mpad, double* dR, double* dV);
 int trsv_forward(gpk_model* m, double* v);                      // v <- L^-1 v  (Npad vector)
 int trsv_backward(gpk_model* m, double* v);                     // v <- L^-T v

@@ -608,6 +608,36 @@ int trsv_backward(gpk_model* m, double* v) {
   return 0;
 }
 
+// Factor m->dK and overwrite v with L^-1 v, the forward substitution riding on the per-panel events of the
+// factorisation like the y substitution of fit_device (its two tiny kernels per panel then cost nothing on top of
+// the factorisation instead of a latency chain of 2 nP launches after it).  Used by the preference-GP Newton loop.
+int potrf_forward(gpk_model* m, double* v) {
+  hipStream_t s = G.s_main, sq = G.s_pred;
+  if (!(sq && m->P == 1 && G.lookahead && G.fuse_predict && m->nP >= 3)) {
+    GPK_TRY(potrf_device(m));
+    return trsv_forward(m, v);
+  }
+  GPK_TRY(ensure_ev_pool(3 * m->nP + 6));
+  hipEvent_t ev_in = G.ev_pool[2 * m->nP + 2];
+  GPK_HIP(hipEventRecord(ev_in, s));  // v and dK are produced on s_main
+  GPK_HIP(hipStreamWaitEvent(sq, ev_in, 0));
+  GPK_TRY(potrf_device(m));
+  if (!g_potrf_lookahead_used) return trsv_forward(m, v);
+  hipEvent_t* ev_panel = G.ev_pool.data();
+  const int np_ = m->Npad;
+  for (int p = 0; p < m->nP; ++p) {
+    const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
+    double* Lp = m->Lpanel(p);
+    GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
+    GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, v + c0, 0, sq));
+    GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, v + c0, v + c0 + w, sq));
+  }
+  hipEvent_t ev_out = G.ev_pool[2 * m->nP + 3];
+  GPK_HIP(hipEventRecord(ev_out, sq));
+  GPK_HIP(hipStreamWaitEvent(s, ev_out, 0));
+  return 0;
+}
+
 // ------------------------------------------------------------------ fused fit (inputs already in HBM)
 static int predict_diag(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s);
 static int predict_update(gpk_model* m, int p, int Mpad, int cg0, int ncols, double* dR, double* dV, hipStream_t s);

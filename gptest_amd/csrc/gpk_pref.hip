@@ -61,8 +61,7 @@ extern "C" int gpk_pref_laplace(gpk_model* m, const long long* uvi, const double
     PREF_HIP(hipMemsetAsync(dr, 0, (size_t)nbp * 8, s));
     PREF_DO(launch_pref_gather(duvi, dkb, dc, npairs, dr, s));                     // C^1/2 D K b
     PREF_DO(launch_pref_build_B(dS, nbp, dc, npairs, nbp, mb->dK, mb->ldk, s));
-    PREF_DO(potrf_device(mb));
-    PREF_DO(trsv_forward(mb, dr));
+    PREF_DO(potrf_forward(mb, dr));                                               // factor B, L_B^-1 (...) riding on it
     PREF_DO(trsv_backward(mb, dr));                                               // B^-1 (...)
     PREF_HIP(hipMemsetAsync(dsv, 0, (size_t)np_ * 8, s));
     PREF_DO(launch_pref_scatter(duvi, dr, dc, 1, npairs, dsv, s));                 // D^T C^1/2 x
