@@ -323,6 +323,9 @@ int dist_update(gpk_model* m, int p, int first_block, int nblocks_max, hipStream
   g.m = rows; g.n = nb_ * m->NB; g.k = w; g.sub = 1; g.lower = 1;
   g.cyc_P = m->P; g.cyc_r = m->r; g.cyc_NB = m->NB; g.cyc_lg0 = first_block;
   g.row_g0 = r0; g.brow_g0 = r0;
+  // a rank's share of an update is 1/P of the tiles: the same latency rule as panel_update (every kernel of
+  // k_gemm.hip rounds identically, so the factor does not depend on the choice)
+  if ((long)(rows / 128) * (g.n / 128) < G.small_tile_below) return launch_gemm_nt(g, false, s);
   return launch_gemm_nt(g, true, s);
 }
 
