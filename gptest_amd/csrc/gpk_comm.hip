@@ -5,6 +5,8 @@
 #include "../../include/gpk.h"
 #include "gpk_core.h"
 #include <rccl/rccl.h>
+#include <cstring>
+#include <vector>
 
 #define GPK_NCCL(x)                                                                                          \
   do {                                                                                                       \
@@ -91,6 +93,43 @@ int gpk_comm_barrier(void) {
   GPK_TRY(gpk_comm_allreduce_max(&x, 1));
   if (G.inited) GPK_HIP(hipDeviceSynchronize());
   return 0;
+}
+
+// Self-check of the RCCL calls this library makes, on a ONE-rank communicator (all a 1-GPU box can host): the same
+// datatypes, counts and streams as the multi-rank path -- panel-sized ncclBroadcast on the high-priority panel
+// stream, ncclAllGather and ncclAllReduce(max) on the CU-masked update stream -- with the payload checked afterwards.
+// It cannot prove anything about links between GPUs; it does prove the calls are accepted on these streams.
+int gpk_test_rccl_selfcheck(int n_doubles) {
+  GPK_TRY(rt_require());
+  if (G.nccl) return gpk_set_err(-1, "gpk_test_rccl_selfcheck: a communicator is already active");
+  if (n_doubles < 1) return gpk_set_err(-1, "gpk_test_rccl_selfcheck: n_doubles=%d", n_doubles);
+  ncclUniqueId id;
+  GPK_NCCL(ncclGetUniqueId(&id));
+  ncclComm_t c;
+  GPK_NCCL(ncclCommInitRank(&c, 1, id, 0));
+  double *a = nullptr, *b = nullptr;
+  int rc = 0;
+  const size_t n = (size_t)n_doubles;
+  if (dev_alloc_t(&a, n) || dev_alloc_t(&b, n)) rc = -2;
+  std::vector<double> h(n), back(n);
+  for (size_t i = 0; i < n; ++i) h[i] = (double)(i % 1000) - 499.5;
+  do {
+    if (rc) break;
+    if (hipMemcpy(a, h.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    ncclResult_t r = ncclBroadcast(a, a, n, ncclDouble, 0, c, G.s_panel);
+    if (r == ncclSuccess) r = ncclAllGather(a, b, n, ncclDouble, c, G.s_main);
+    if (r == ncclSuccess) r = ncclAllReduce(b, b, n, ncclDouble, ncclMax, c, G.s_main);
+    if (r != ncclSuccess) { rc = gpk_set_err(-3, "RCCL call failed: %s", ncclGetErrorString(r)); break; }
+    if (hipDeviceSynchronize() != hipSuccess) { rc = gpk_set_err(-2, "sync after RCCL calls failed: %s", hipGetErrorString(hipGetLastError())); break; }
+    if (hipMemcpy(back.data(), b, n * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
+    for (size_t i = 0; i < n; ++i)
+      if (back[i] != h[i]) { rc = gpk_set_err(-3, "payload mismatch at %zu", i); break; }
+  } while (0);
+  if (a) dev_free(a, n * 8);
+  if (b) dev_free(b, n * 8);
+  (void)hipDeviceSynchronize();
+  ncclCommDestroy(c);
+  return rc;
 }
 
 int gpk_comm_destroy(void) {

@@ -131,6 +131,9 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
 /* C (m x n) = [C -] A (m x k) * B (n x k)^T through the MFMA kernel; tile = 128 or 64. */
 int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile);
 /* single-GPU emulation of the P-rank block-cyclic Cholesky (RCCL broadcast replaced by D2D copies). */
+/* the RCCL calls of the multi-rank path (broadcast on the panel stream, all-gather and all-reduce on the update
+ * stream) on a one-rank communicator, payload checked: what a 1-GPU box can verify of gpk_comm.hip. */
+int gpk_test_rccl_selfcheck(int n_doubles);
 int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out);
 /* same emulation, every virtual rank builds its own block columns of K(X,X) on the device first. */
 int gpk_test_dist_fit(const double* X, int N, int d, const double* log_hyp, double jitter, int P, double* L_out);

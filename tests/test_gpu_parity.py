@@ -615,3 +615,9 @@ def test_option_paths_keep_parity(gpk, opts):
     assert abs(nlml - nl) <= RTOL * abs(nl)
     np.testing.assert_allclose(mean, fz, rtol=RTOL, atol=RTOL * np.abs(fz).max())
     np.testing.assert_allclose(var, cov, rtol=RTOL, atol=RTOL * np.abs(cov).max())
+
+
+def test_rccl_calls_on_a_one_rank_communicator(gpk):
+    """All a 1-GPU box can check of gpk_comm.hip: panel-sized ncclBroadcast on the panel stream, ncclAllGather and
+    ncclAllReduce on the CU-masked update stream, on a one-rank communicator, payload intact."""
+    assert gpk.lib().gpk_test_rccl_selfcheck(16384 * 256) == 0, gpk.last_error()
