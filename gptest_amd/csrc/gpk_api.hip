@@ -65,7 +65,16 @@ int gpk_init(int device) {
     hipError_t e2 = e1 != hipSuccess ? e1
                     : panel_prio     ? hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, phi)
                                      : hipExtStreamCreateWithCUMask(&G.s_panel, words, m_all.data());
-    hipError_t e3 = e2 == hipSuccess ? hipExtStreamCreateWithCUMask(&G.s_leaf, words, m_leaf.data()) : e2;
+    // The leaf runs on the panel chain's stream (leaf_direct_rows): that stream is unmasked, and the CUs the update
+    // stream's mask leaves out are where its 1024-thread workgroup finds room.  A leaf stream of its own (masked to
+    // those CUs, two event hops per leaf) is only created on request: GPK_LEAF_STREAM=1.
+    const char* env_ls = getenv("GPK_LEAF_STREAM");
+    const bool leaf_stream = env_ls && env_ls[0] == '1';
+    hipError_t e3 = e2;
+    if (e2 == hipSuccess) {
+      if (leaf_stream) e3 = hipExtStreamCreateWithCUMask(&G.s_leaf, words, m_leaf.data());
+      else G.s_leaf = G.s_panel;
+    }
     if (e3 == hipSuccess) {
       // s_pred (forward substitutions pipelined behind the panels): priority instead of a mask, otherwise its
       // kernels queue behind thousands of trailing-update workgroups and the whole backlog (2.7 ms measured)
@@ -73,7 +82,8 @@ int gpk_init(int device) {
       // The y substitution shares this stream.  Stream COUNT matters on this part: with the y chain on a stream
       // of its own the posterior rate at N = 16384 was 23.6 (high priority) / 24.8 (normal) against 25.6 here,
       // one further idle high-priority stream took it to 19-20, and moving the substitutions onto the panel
-      // chain's stream (three streams) to 22.4: four streams -- update, leaf, panel chain, substitutions.
+      // chain's stream to 22.4.  Dropping the leaf stream as well (see above) leaves three: update, panel chain,
+      // substitutions.
       const char* env_qp = getenv("GPK_PRED_PRIO");
       if (env_qp && env_qp[0] == '0') e3 = hipExtStreamCreateWithCUMask(&G.s_pred, words, m_all.data());
       else if (env_qp && env_qp[0] == '2') e3 = hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, (plo + phi) / 2);
@@ -156,7 +166,7 @@ void gpk_shutdown(void) {
     SD_STEP("destroy s_main", if (G.s_main) (void)hipStreamDestroy(G.s_main));
     SD_STEP("destroy s_leaf", if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf));
   }
-  SD_STEP("destroy s_panel", if (G.s_panel && (destroy_masked || G.s_leaf != G.s_panel)) (void)hipStreamDestroy(G.s_panel));
+  SD_STEP("destroy s_panel", if (G.s_panel) (void)hipStreamDestroy(G.s_panel));
   SD_STEP("destroy events", {
     for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
     for (hipEvent_t e : G.ev_pool) (void)hipEventDestroy(e);
