@@ -40,36 +40,80 @@ def synthetic_problem(N, d, M, seed=1234):
     return X, y, Z, log_hyp
 
 
-def cpu_baseline(N, d, M, budget_n=4096):
-    """The oracle (verbatim-cost restatement of GPr.py) timed on the host cores, on a bounded
-    sample: one posterior at N_s = budget_n, scaled by (N/N_s)^3 (all dominant terms are n^3)."""
-    from oracle import gpr_oracle as orc
-
-    X, y, Z, lh = orc.synthetic_problem(budget_n, d, M)
-    t0 = time.perf_counter()
-    orc.posterior_verbatim(lh, X, y, Z)
-    t = time.perf_counter() - t0
-    scale = (N / float(budget_n)) ** 3
-    cores = None
+def _blas_info():
+    cores, name = None, None
     try:
         from threadpoolctl import threadpool_info
 
-        cores = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [None])
+        blas = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+        if blas:
+            cores = max(p.get("num_threads", 1) for p in blas)
+            name = ", ".join(sorted({"%s %s" % (p.get("internal_api", "?"), p.get("version", "")) for p in blas}))
     except Exception:
-        cores = None
+        pass
     if not cores:
         try:
             cores = len(os.sched_getaffinity(0))
         except Exception:
             cores = os.cpu_count() or 1
+    return cores, name
+
+
+def cpu_baseline(N, d, M, budget_n=4096, budget_n_eff=8192):
+    """The oracle timed on the host cores, on bounded samples (all dominant terms are n^3):
+    * the verbatim-cost restatement of GPr.py (inv + cholesky + two LU solves against eye(n), GPr.py:45-69) at
+      N_s = budget_n, scaled by (N/N_s)^3 -- the reference's own algorithm, the headline "port" figure;
+    * the efficient flavour (SciPy cho/triangular solves, one shared factorisation: the algorithm the HIP path
+      implements) at N_s = budget_n_eff, scaled the same way -- BASELINE.md section 3 asks for both."""
+    from oracle import gpr_oracle as orc
+
+    cores, blas = _blas_info()
+    X, y, Z, lh = orc.synthetic_problem(min(budget_n, N), d, M)
+    t0 = time.perf_counter()
+    orc.posterior_verbatim(lh, X, y, Z)
+    t = time.perf_counter() - t0
+    scale = (N / float(len(X))) ** 3
+    X2, y2, Z2, lh2 = orc.synthetic_problem(min(budget_n_eff, N), d, M)
+    t0 = time.perf_counter()
+    orc.posterior_efficient(lh2, X2, y2, Z2)
+    t2 = time.perf_counter() - t0
+    scale2 = (N / float(len(X2))) ** 3
     return {
         "value": 1.0 / (t * scale),
         "unit": "posteriors/s",
         "cores": cores,
+        "blas": blas,
         "kind": "port",
         "sample": "one verbatim-cost posterior (inv + cholesky + 2 LU solves, GPr.py:45-69) at N=%d d=%d M=%d "
-                  "took %.2f s; n^3-scaled x%.0f to N=%d" % (budget_n, d, M, t, scale, N),
+                  "took %.2f s; n^3-scaled x%.0f to N=%d" % (len(X), d, M, t, scale, N),
+        "efficient": {
+            "value": 1.0 / (t2 * scale2),
+            "unit": "posteriors/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "one efficient posterior (scipy cholesky + triangular solves, one shared factorisation) at "
+                      "N=%d d=%d M=%d took %.2f s; n^3-scaled x%.0f to N=%d" % (len(X2), d, M, t2, scale2, N),
+        },
     }
+
+
+def parity_check(N, d, M, nlml, mean, var, lh):
+    """Compare this run's outputs with the committed full-size fixture (tests/golden/full_*.npz, written by
+    tests/golden/make_fullsize.py from the CPU oracle).  Returns (checked, detail, ok); ok is False on a mismatch
+    beyond the north-star bar of 1e-6 relative: a fast kernel with wrong results must not print a headline
+    (main() then exits with status 4 after the closing barrier, so that no other rank is left waiting)."""
+    name = {(16384, 8, 1024): "c3_16384_d8", (4096, 4, 1024): "c2_4096_d4"}.get((N, d, M))
+    if name is None:
+        return False, "no committed fixture for N=%d d=%d M=%d" % (N, d, M), True
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_%s.npz" % name))
+    ref = float(g["nlml"])
+    e_nl = abs(nlml - ref) / abs(ref)
+    e_mean = float(np.abs(mean - g["fz"]).max() / np.abs(g["fz"]).max())
+    e_var = float(np.abs(var - g["cov_fz"]).max() / np.exp(lh[-2]) ** 2)
+    detail = {"fixture": "tests/golden/full_%s.npz" % name, "rel_err_nlml": e_nl, "rel_err_mean": e_mean,
+              "err_var_over_sf2": e_var, "tol": 1e-6}
+    ok = bool(e_nl <= 1e-6 and e_mean <= 1e-6 and e_var <= 1e-6)
+    return ok, detail, ok
 
 
 def main():
@@ -131,7 +175,9 @@ def main():
         l.gpk_last_timing_work(name.encode(), ctypes.byref(a))
         return a.value
 
+    parity_ok = True
     if rank == 0:
+        checked, parity_detail, parity_ok = parity_check(N, d, M, nlml.value, mean, var, lh)
         nb = int(l.gpk_get_option(b"nb"))
         tr_ms, tr_n = stage("trailing")
         kb_ms, kb_n = stage("kbuild")
@@ -183,16 +229,24 @@ def main():
                        "frac": kb_bytes / (kb_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if kb_ms else None,
                        "note": "only the lower-triangle tiles are written: 4*N^2 + 8*N*d algorithmic bytes per build"},
             "nlml": nlml.value,
+            "parity_checked": checked,
+            "parity": parity_detail,
             "wall_s_incl_staging": wall,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, d, M)
-        print(json.dumps(out), flush=True)
+        if parity_ok:
+            print(json.dumps(out), flush=True)
+        else:
+            sys.stderr.write("bench.py: PARITY FAILURE, no result line printed: %s\n" % json.dumps(out))
+            sys.stderr.flush()
     _lib.check(l.gpk_comm_barrier(), "barrier")
     l.gpk_comm_destroy()
     # everything is measured and printed: release the GPU objects explicitly (a profiler attached to this process
     # needs that for a clean exit), but never let the release keep the process alive
     _lib.shutdown(full=True, watchdog_s=20.0)
+    if rank == 0 and not parity_ok:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

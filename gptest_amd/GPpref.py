@@ -21,6 +21,7 @@ retried with 10x jitter on ``LinAlgError`` (GPpref.py:126-135).  Parity for this
 reference cannot be imported: Python-2 + GPy); the tests compare against a NumPy restatement of GPpref.py.
 """
 import ctypes
+import warnings
 
 import numpy as np
 
@@ -114,7 +115,8 @@ class PreferenceGaussianProcess(object):
         self.delta_f = delta_f
         self.likelihood = likelihood()
         self.kern = _RBFParams(self._xdim)
-        self.max_iter = 100      # the reference loops without a bound (GPpref.py:140)
+        self.max_iter = 100      # the reference loops without a bound (GPpref.py:140); see last_converged
+        self.last_converged = None
         self.verbose = False     # the reference prints f_error, lml every iteration (GPpref.py:154)
         self.last_iterations = 0
         self.last_eps = None
@@ -132,6 +134,10 @@ class PreferenceGaussianProcess(object):
         # K = variance * exp(-r^2/2), no noise term: log sigma_n = -inf; jitter eps on the diagonal
         lh = np.concatenate([loghyp[0:self._xdim], [loghyp[self._xdim]], [-np.inf]])
         eps = 1e-6
+        # GPpref.py:126-135 retries with 10x the jitter for ever.  K + eps I with |K_ij| <= variance is positive
+        # definite for certain once eps > nx * variance; a failure beyond that means the inputs are not finite
+        # (NaN in x_train makes every retry fail), so the loop is bounded there and raises.
+        eps_cap = 10.0 * max(1.0, float(self._nx) * float(self.kern.variance))
         while True:
             try:
                 handle, _ = fit_handle(self.x_train, None, lh, jitter=eps, keep_k=True)
@@ -140,6 +146,10 @@ class PreferenceGaussianProcess(object):
                 eps = eps * 10
                 if self.verbose:
                     print("Inversion issue, adding noise: {0}".format(eps))
+                if not (eps <= eps_cap):
+                    raise np.linalg.LinAlgError(
+                        "K + eps*I is not positive definite even with eps = %g: non-finite inputs or "
+                        "hyper-parameters?" % eps)
         self.last_eps = eps
         uvi = np.ascontiguousarray(self.uvi_train, dtype=np.int64)
         y = np.ascontiguousarray(np.asarray(self.y_train, dtype=np.float64).reshape(-1))
@@ -156,6 +166,13 @@ class PreferenceGaussianProcess(object):
         _lib.check(rc, "gpk_pref_laplace")
         self.last_iterations = iters.value
         self.last_trace = trace[:iters.value].copy()
+        # the reference iterates until f_error <= delta_f whatever it takes (GPpref.py:140); this loop stops at
+        # max_iter and says so instead of returning a non-converged mode silently
+        self.last_converged = bool(iters.value > 0 and not (self.last_trace[-1] > self.delta_f))
+        if not self.last_converged:
+            warnings.warn("calc_laplace: Newton loop stopped after max_iter=%d iterations with f_error=%g > "
+                          "delta_f=%g" % (self.max_iter, self.last_trace[-1] if iters.value else float("nan"),
+                                          self.delta_f), RuntimeWarning)
         self._mode = (handle, uvi, y, fv.copy())   # kept in HBM / on the host for predict_latent
         if self.verbose:
             for e in self.last_trace:

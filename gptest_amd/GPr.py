@@ -9,6 +9,7 @@ argument marshalling.  Extension over the reference: (N,d) inputs with d > 1
 (the reference's squared_distance is 1-D only, GPr.py:5-6).
 """
 import ctypes
+import hashlib
 
 import numpy as np
 
@@ -166,11 +167,23 @@ class GaussianProcess(object):
         self._cache_key = None
         self._cache = None
 
+    def _key(self, lh):
+        """Cache key of a factorisation: the hyper-parameters AND the training data as they are now.  The reference
+        re-reads self.trainInput / self.trainTarget on every call (GPr.py:47,59-61), so reassigning or mutating them
+        in place must invalidate the cached factor: a digest of the bytes (1 MiB at N = 16384, d = 8: < 1 ms)."""
+        h = hashlib.blake2b(digest_size=16)
+        h.update(np.ascontiguousarray(lh, dtype=np.float64).tobytes())
+        for a in (self.trainInput, self.trainTarget):
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+            h.update(repr(a.shape).encode())
+            h.update(a.tobytes())
+        return h.digest()
+
     def _fitted(self, hyp):
-        """One K build + one factorisation per distinct hyper-parameter vector (the reference
+        """One K build + one factorisation per distinct (hyper-parameters, data) (the reference
         rebuilds and refactors on every call, GPr.py:47-48,59-63; results are identical)."""
         lh = np.ascontiguousarray(hyp, dtype=np.float64)
-        key = lh.tobytes()
+        key = self._key(lh)
         if self._cache_key != key:
             self._cache = fit_handle(self.trainInput, self.trainTarget, lh)
             self._cache_key = key
@@ -185,7 +198,8 @@ class GaussianProcess(object):
         fz, fzp = _lib.out_array(Z.shape[0])
         cov, covp = _lib.out_array(Z.shape[0])
         lh = np.ascontiguousarray(self.covFun.logHyp, dtype=np.float64)
-        if self._cache_key != lh.tobytes():
+        key = self._key(lh)
+        if self._cache_key != key:
             # nothing factored yet for these hyper-parameters: one fused call (K build, Cholesky and the
             # prediction solve pipelined behind it), and the handle is kept for later calls
             _lib.init()
@@ -202,7 +216,7 @@ class GaussianProcess(object):
                                             ctypes.byref(nlml), fzp, covp)
             _lib.check(rc, "gpk_fit_predict")
             self._cache = (_Handle(h), nlml.value)
-            self._cache_key = lh.tobytes()
+            self._cache_key = key
             return fz, cov
         handle, _ = self._fitted(self.covFun.logHyp)
         rc = _lib.lib().gpk_predict(handle.ptr, Z.ctypes.data_as(_lib.c_double_p), Z.shape[0], fzp, covp)

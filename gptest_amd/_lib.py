@@ -67,6 +67,7 @@ def _bind(l):
         "gpk_test_potf2_128": (i, [dp, dp, dp]),
         "gpk_test_dist_potrf": (i, [dp, i, i, dp]),
         "gpk_test_dist_fit": (i, [dp, i, i, dp, d, i, dp]),
+        "gpk_test_dist_posterior": (i, [dp, dp, i, i, dp, dp, i, i, dp, dp, dp]),
         "gpk_bench_se_build": (i, [i, i, i, i, i, dp]),
         "gpk_bench_gemm_nt": (i, [i, i, i, i, i, i, dp]),
         "gpk_bench_mfma_peak": (i, [i, dp]),
@@ -142,8 +143,9 @@ def init(device=None):
 def shutdown(full=True, watchdog_s=None):
     """Release streams, events and pooled HBM.  ``full=False`` (what the interpreter-exit handler uses) leaves the
     CU-masked streams to process teardown: their hipStreamDestroy has been seen to hang in one scenario, and an exit
-    handler must never hang.  ``watchdog_s``: run the release on a helper thread and hard-exit the process with
-    status 0 if it has not returned in time (for scripts whose work is done and printed, e.g. bench.py)."""
+    handler must never hang.  ``watchdog_s``: run the release on a helper thread; if it has not returned in time the
+    process is ended with exit status 3 (a stuck teardown is a failure and must be visible to whoever launched the
+    script, even though its results are already printed)."""
     global _inited
     if _lib is None or not _inited:
         _inited = False
@@ -161,9 +163,10 @@ def shutdown(full=True, watchdog_s=None):
     t.join(watchdog_s)
     if t.is_alive():
         sys.stdout.flush()
-        sys.stderr.write("gptest_amd: gpk_shutdown did not return within %.0f s, leaving the rest to process teardown\n" % watchdog_s)
+        sys.stderr.write("gptest_amd: gpk_shutdown did not return within %.0f s (set GPK_TRACE_SHUTDOWN=1 to see the "
+                         "step); exiting with status 3\n" % watchdog_s)
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(3)
 
 
 def _shutdown_at_exit():

@@ -120,13 +120,16 @@ int gpk_init(int device) {
     // Touch every stream once.  The runtime builds a stream's hardware queue lazily; destroying a CU-masked
     // stream whose queue was never built hangs in hipStreamDestroy (seen at interpreter exit of a process that
     // only ever used the update stream), and the first real launch on each stream no longer pays for the build.
-    unsigned long long* dtouch = nullptr;
-    GPK_HIP(hipMalloc((void**)&dtouch, 64));
-    hipStream_t all[4] = {G.s_main, G.s_panel, G.s_leaf, G.s_pred};
-    for (int i = 0; i < 4; ++i)
-      if (all[i]) GPK_TRY(launch_stamp(dtouch + i, all[i]));
-    GPK_HIP(hipDeviceSynchronize());
-    (void)hipFree(dtouch);
+    const char* env_nt = getenv("GPK_NO_TOUCH");  // diagnostic (scripts/shutdown_probe.py)
+    if (!(env_nt && env_nt[0] == '1')) {
+      unsigned long long* dtouch = nullptr;
+      GPK_HIP(hipMalloc((void**)&dtouch, 64));
+      hipStream_t all[4] = {G.s_main, G.s_panel, G.s_leaf, G.s_pred};
+      for (int i = 0; i < 4; ++i)
+        if (all[i]) GPK_TRY(launch_stamp(dtouch + i, all[i]));
+      GPK_HIP(hipDeviceSynchronize());
+      (void)hipFree(dtouch);
+    }
   }
   G.inited = true;
   return 0;
@@ -169,11 +172,11 @@ void gpk_shutdown(void) {
   SD_STEP("destroy s_panel", if (G.s_panel) (void)hipStreamDestroy(G.s_panel));
   SD_STEP("destroy events", {
     for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
-    for (hipEvent_t e : G.ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : G.ev_dep_free) (void)hipEventDestroy(e);
   });
 #undef SD_STEP
   G.ev_ring.clear();
-  G.ev_pool.clear();
+  G.ev_dep_free.clear();
   G.s_main = G.s_panel = G.s_leaf = nullptr;
   G.inited = false;
 }
@@ -233,6 +236,8 @@ int gpk_set_option(const char* key, double value) {
     G.pipe_interleave = (int)value;
   } else if (k == "fuse_predict") {
     G.fuse_predict = (int)value;
+  } else if (k == "solve_gemm_above") {
+    G.solve_gemm_above = (int)value;
   } else if (k == "timing") {
     G.timing = (int)value;
     if (!G.timing) timers_reset();
@@ -250,6 +255,25 @@ double gpk_get_option(const char* key) {
   if (k == "potrf_enqueue_ms") return G.last_potrf_enqueue_ms;
   if (k == "pipe_enqueue_ms") return G.last_pipe_enqueue_ms;
   if (k == "cu_reserved") return G.cu_reserved ? 1.0 : 0.0;
+  if (k == "potrf_lookahead_used") return g_potrf_lookahead_used;
+  if (k == "dist_lookahead_used") return g_dist_lookahead_used;
+  if (k == "nb_auto") return G.nb_auto;
+  if (k == "nb_big") return G.nb_big;
+  if (k == "nb_big_until") return G.nb_big_until;
+  if (k == "nb_small") return G.nb_small;
+  if (k == "nb_small_from") return G.nb_small_from;
+  if (k == "xcd_sq") return G.xcd_sq;
+  if (k == "leaf_direct_rows") return G.leaf_direct_rows;
+  if (k == "pred_small_below") return G.pred_small_below;
+  if (k == "small_tile_below") return G.small_tile_below;
+  if (k == "pair_update") return G.pair_update;
+  if (k == "pipe_interleave") return G.pipe_interleave;
+  if (k == "fuse_predict") return G.fuse_predict;
+  if (k == "solve_gemm_above") return G.solve_gemm_above;
+  if (k == "stamps") return G.stamps;
+  if (k == "test_gemm_k1") return G.test_gemm_k1;
+  if (k == "leaf_algo") { extern int g_leaf_algo; return g_leaf_algo; }
+  if (k == "gemm_variant") { extern int g_gemm_variant; return g_gemm_variant; }
   // diagnostic stamps of the last fused fit: "stamp_panel_<p>" / "stamp_subst_<p>" in ms after panel 0
   if (k.rfind("stamp_", 0) == 0 && G.hstamps.size() == 1024 && G.hstamps[0]) {
     const bool subst = k.rfind("stamp_subst_", 0) == 0;
@@ -452,27 +476,62 @@ int gpk_predict(gpk_model* m, const double* Z, int M, double* mean_out, double* 
   return rc;
 }
 
+// K^-1 B (backward) or L^-1 B for B (N x nrhs, row-major).  Few right-hand sides: the single-vector substitution
+// kernels, one column after the other, ONE transfer each way.  Many (the explicit-inverse use of GPr.py:63 and
+// GPpref.py:129 has nrhs = N): the rows of B^T go through the blocked substitutions on the MFMA GEMM
+// (rows_forward_solve / rows_backward_solve), also one transfer each way.
 static int solve_common(gpk_model* m, const double* B, int nrhs, double* X_out, bool backward) {
   GPK_TRY(rt_require());
   if (!m || !B || !X_out) return gpk_set_err(-1, "gpk_solve: null pointer");
   if (nrhs < 1) return gpk_set_err(-1, "gpk_solve: nrhs=%d must be >= 1", nrhs);
+  if (m->P != 1) return gpk_set_err(-1, "gpk_solve: single-GPU models only");
   hipStream_t s = G.s_main;
   const int N = m->N, np_ = m->Npad;
-  double* dv = nullptr;
-  GPK_TRY(dev_alloc_t(&dv, (size_t)np_));
-  std::vector<double> col(np_, 0.0);
+  const int Mpad = round_up(nrhs, 128);
+  const size_t szB = (size_t)N * nrhs, szR = (size_t)Mpad * np_;
+  const bool gemm_path = nrhs > G.solve_gemm_above;
+  double *dB = nullptr, *dR = nullptr, *dV = nullptr, *dU = nullptr, *dDT = nullptr;
   int rc = 0;
-  for (int j = 0; j < nrhs && !rc; ++j) {
-    for (int i = 0; i < N; ++i) col[i] = B[(size_t)i * nrhs + j];
-    if (hipMemcpyAsync(dv, col.data(), (size_t)np_ * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    rc = trsv_forward(m, dv);
-    if (!rc && backward) rc = trsv_backward(m, dv);
-    if (rc) break;
-    if (hipMemcpyAsync(col.data(), dv, (size_t)N * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "solve: %s", hipGetErrorString(hipGetLastError())); break; }
-    for (int i = 0; i < N; ++i) X_out[(size_t)i * nrhs + j] = col[i];
+  rc |= dev_alloc_t(&dB, szB);
+  rc |= dev_alloc_t(&dR, szR);
+  if (gemm_path) {
+    rc |= dev_alloc_t(&dV, szR);
+    if (backward) {
+      rc |= dev_alloc_t(&dU, (size_t)np_ * np_);
+      rc |= dev_alloc_t(&dDT, (size_t)m->nT * 128 * 128);
+    }
   }
-  dev_free(dv, (size_t)np_ * 8);
+  auto body = [&]() -> int {
+    GPK_HIP(hipMemcpyAsync(dB, B, szB * 8, hipMemcpyHostToDevice, s));
+    GPK_HIP(hipMemsetAsync(dR, 0, szR * 8, s));
+    GPK_TRY(launch_transpose(dB, nrhs, N, nrhs, dR, np_, s));  // rows of dR = right-hand sides, zero padded
+    const double* res = dR;
+    if (!gemm_path) {
+      for (int j = 0; j < nrhs; ++j) {
+        GPK_TRY(trsv_forward(m, dR + (size_t)j * np_));
+        if (backward) GPK_TRY(trsv_backward(m, dR + (size_t)j * np_));
+      }
+    } else {
+      GPK_TRY(rows_forward_solve(m, Mpad, dR, dV));
+      res = dV;
+      if (backward) {
+        GPK_TRY(rows_backward_prepare(m, dU, dDT, s));
+        GPK_TRY(rows_backward_solve(m, Mpad, dV, dR, dU, dDT));  // dR is free again after the forward sweep
+        res = dR;
+      }
+    }
+    GPK_TRY(launch_transpose(res, np_, nrhs, N, dB, nrhs, s));
+    GPK_HIP(hipMemcpyAsync(X_out, dB, szB * 8, hipMemcpyDeviceToHost, s));
+    if (hipStreamSynchronize(s) != hipSuccess) return gpk_set_err(-2, "solve: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+  };
+  if (!rc) rc = body();
+  if (rc) (void)hipStreamSynchronize(s);
+  if (dB) dev_free(dB, szB * 8);
+  if (dR) dev_free(dR, szR * 8);
+  if (dV) dev_free(dV, szR * 8);
+  if (dU) dev_free(dU, (size_t)np_ * np_ * 8);
+  if (dDT) dev_free(dDT, (size_t)m->nT * 128 * 128 * 8);
   return rc;
 }
 int gpk_solve(gpk_model* m, const double* B, int nrhs, double* X_out) { return solve_common(m, B, nrhs, X_out, true); }
@@ -677,76 +736,64 @@ __global__ void pad_diag_local_kernel(double* K, long ldk, int N, int Npad, int 
 
 extern "C" {
 
-static int dist_emulate_factor(std::vector<gpk_model*>& ms, int N, double* L_out) {
-  const int P = (int)ms.size();
-  hipStream_t s = G.s_main;
-  const int nP = ms[0]->nP, np_ = ms[0]->Npad;
-  int rc = 0;
-  {
-    for (int p = 0; p < nP && !rc; ++p) {
-      gpk_model* own = ms[p % P];
-      rc = factor_panel(own, p, s);
-      const int c0 = own->pc0[p], w = own->pw[p];
-      for (int r = 0; r < P && !rc; ++r) {
-        if (r == p % P) continue;
-        if (hipMemcpyAsync(ms[r]->Lpanel(p), own->Lpanel(p), (size_t)(np_ - c0) * w * 8, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-            hipMemcpyAsync(ms[r]->dDinv + (size_t)(c0 / 128) * 16384, own->dDinv + (size_t)(c0 / 128) * 16384,
-                           (size_t)(w / 128) * 16384 * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
-          rc = gpk_set_err(-2, "D2D failed");
-      }
-      for (int r = 0; r < P && !rc; ++r) {
-        gpk_model* m = ms[r];
-        const int lg0 = (p >= r) ? (p - r) / P + 1 : 0;
-        rc = (P > 1) ? dist_update(m, p, lg0, 1 << 30, s)
-                     : panel_update(m, p, c0 + w, c0 + w, np_ - c0 - w, 1, s);
-      }
-    }
-    int worst = 0;
-    for (int r = 0; r < P && !rc; ++r) {
-      int hinfo = 0;
-      if (hipMemcpyAsync(&hinfo, ms[r]->dinfo, 4, hipMemcpyDeviceToHost, s) != hipSuccess) rc = gpk_set_err(-2, "D2H failed");
-      if (hipStreamSynchronize(s) != hipSuccess) rc = gpk_set_err(-2, "dist potrf: %s", hipGetErrorString(hipGetLastError()));
-      if (hinfo > worst) worst = hinfo;
-    }
-    if (!rc && worst > 0) rc = worst > N ? N : worst;
-    if (!rc) rc = model_unpack_L(ms[P - 1], L_out);
+// Single-GPU emulation of a P-rank block-cyclic job: P rank models live in this process and are driven through
+// the production group entry points (potrf_group / fit_group / predict_group), i.e. the very phases, stream and
+// event order a real rank runs; only the RCCL broadcast / all-gather are device copies from the peer's model.
+struct VirtualJob {
+  std::vector<gpk_model*> ms;
+  ~VirtualJob() {
+    for (gpk_model* m : ms)
+      if (m) model_destroy(m);
   }
-  return rc;
+  int create(int N, int d, int P) {
+    ms.assign(P, nullptr);
+    for (int r = 0; r < P; ++r) GPK_TRY(model_create(&ms[r], N, d, false, P, r));
+    for (int r = 0; r < P; ++r) ms[r]->vgroup = ms.data();
+    return 0;
+  }
+};
+
+static int virtual_job_check_info(VirtualJob& job, int N) {
+  hipStream_t s = G.s_main;
+  int worst = 0;
+  for (gpk_model* m : job.ms) {
+    int hinfo = 0;
+    GPK_HIP(hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipStreamSynchronize(s));
+    if (hinfo > worst) worst = hinfo;
+  }
+  if (worst > 0) return worst > N ? N : worst;
+  return 0;
 }
 
-// Single-GPU emulation of the P-rank block-cyclic factorisation: P rank models live in this process,
-// the RCCL broadcast is replaced by device-to-device copies, everything else (ownership, local column
-// maps, the cyclic GEMM column map) is the production code.  L of rank `P-1` is returned.
+// L of rank P-1 is returned.  P = 1 is the production single-GPU factorisation (potrf_device).
 int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
   GPK_TRY(rt_require());
   if (!A || !L_out || N < 1 || P < 1 || P > 16) return gpk_set_err(-1, "gpk_test_dist_potrf: bad arguments");
   hipStream_t s = G.s_main;
-  std::vector<gpk_model*> ms(P, nullptr);
-  int rc = 0;
-  for (int r = 0; r < P && !rc; ++r) rc = model_create(&ms[r], N, 1, false, P, r);
-  if (!rc) {
-    const int NB = ms[0]->NB, np_ = ms[0]->Npad;
-    for (int r = 0; r < P && !rc; ++r) {
-      gpk_model* m = ms[r];
-      if (hipMemsetAsync(m->dK, 0, (size_t)np_ * m->ldk * 8, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
-      if (hipMemsetAsync(m->dinfo, 0, 16, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
-      for (int lg = 0; lg < m->nloc && !rc; ++lg) {
-        const int g = (P > 1) ? lg * P + r : lg;
-        const int cg0 = g * NB;
-        int nc = N - cg0;
-        if (nc > NB) nc = NB;
-        if (nc <= 0) continue;
-        if (hipMemcpy2DAsync(m->dK + (size_t)lg * NB, (size_t)m->ldk * 8, A + cg0, (size_t)N * 8, (size_t)nc * 8, N,
-                             hipMemcpyHostToDevice, s) != hipSuccess)
-          rc = gpk_set_err(-2, "H2D failed");
-      }
-      if (!rc && np_ > N) hipLaunchKernelGGL(pad_diag_local_kernel, dim3(8), dim3(256), 0, s, m->dK, m->ldk, N, np_, NB, P, r);
+  VirtualJob job;
+  GPK_TRY(job.create(N, 1, P));
+  const int NB = job.ms[0]->NB, np_ = job.ms[0]->Npad;
+  for (int r = 0; r < P; ++r) {
+    gpk_model* m = job.ms[r];
+    GPK_HIP(hipMemsetAsync(m->dK, 0, (size_t)np_ * m->ldk * 8, s));
+    if (P == 1) {
+      GPK_HIP(hipMemcpy2DAsync(m->dK, (size_t)m->ldk * 8, A, (size_t)N * 8, (size_t)N * 8, N, hipMemcpyHostToDevice, s));
+      if (np_ > N) hipLaunchKernelGGL(pad_identity_kernel, dim3(1024), dim3(256), 0, s, m->dK, m->ldk, N, np_);
+      continue;
     }
-    if (!rc) rc = dist_emulate_factor(ms, N, L_out);
+    for (int lg = 0; lg < m->nloc; ++lg) {
+      const int cg0 = (lg * P + r) * NB;
+      const int nc = std::min(NB, N - cg0);
+      if (nc <= 0) continue;
+      GPK_HIP(hipMemcpy2DAsync(m->dK + (size_t)lg * NB, (size_t)m->ldk * 8, A + cg0, (size_t)N * 8, (size_t)nc * 8, N,
+                               hipMemcpyHostToDevice, s));
+    }
+    if (np_ > N) hipLaunchKernelGGL(pad_diag_local_kernel, dim3(8), dim3(256), 0, s, m->dK, m->ldk, N, np_, NB, P, r);
   }
-  for (int r = 0; r < P; ++r)
-    if (ms[r]) model_destroy(ms[r]);
-  return rc;
+  GPK_TRY(P == 1 ? potrf_device(job.ms[0]) : potrf_group(job.ms.data(), P));
+  GPK_TRY(virtual_job_check_info(job, N));
+  return model_unpack_L(job.ms[P - 1], L_out);
 }
 
 int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile) {
@@ -828,19 +875,50 @@ extern "C" int gpk_test_dist_fit(const double* X, int N, int d, const double* lo
   GPK_TRY(rt_require());
   if (!X || !log_hyp || !L_out || N < 1 || P < 1 || P > 16) return gpk_set_err(-1, "gpk_test_dist_fit: bad arguments");
   hipStream_t s = G.s_main;
-  std::vector<gpk_model*> ms(P, nullptr);
-  int rc = 0;
-  for (int r = 0; r < P && !rc; ++r) rc = model_create(&ms[r], N, d, false, P, r);
-  for (int r = 0; r < P && !rc; ++r) {
-    gpk_model* m = ms[r];
-    rc = decode_hyp(log_hyp, d, jitter, m);
-    if (!rc && hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
-    if (!rc && hipMemsetAsync(m->dinfo, 0, 16, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
-    if (!rc) rc = build_K(m);
+  VirtualJob job;
+  GPK_TRY(job.create(N, d, P));
+  for (gpk_model* m : job.ms) {
+    GPK_TRY(decode_hyp(log_hyp, d, jitter, m));
+    GPK_HIP(hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s));
   }
-  if (!rc) rc = dist_emulate_factor(ms, N, L_out);
-  for (int r = 0; r < P; ++r)
-    if (ms[r]) model_destroy(ms[r]);
+  GPK_TRY(P == 1 ? fit_device(job.ms[0]) : fit_group(job.ms.data(), P));
+  return model_unpack_L(job.ms[P - 1], L_out);
+}
+
+// The whole posterior of a P-rank job (fit + sharded prediction + emulated all-gather) on P virtual ranks.
+// nlml_out[P], mean_out / var_out [P][M]: what every rank ends up with (they must all agree).
+extern "C" int gpk_test_dist_posterior(const double* X, const double* y, int N, int d, const double* log_hyp,
+                                       const double* Z, int M, int P, double* nlml_out, double* mean_out,
+                                       double* var_out) {
+  GPK_TRY(rt_require());
+  if (!X || !y || !log_hyp || !Z || !nlml_out || !mean_out || !var_out || N < 1 || M < 1 || P < 2 || P > 16)
+    return gpk_set_err(-1, "gpk_test_dist_posterior: bad arguments");
+  hipStream_t s = G.s_main;
+  VirtualJob job;
+  GPK_TRY(job.create(N, d, P));
+  double* dZ = nullptr;
+  GPK_TRY(dev_alloc_t(&dZ, (size_t)M * d));
+  auto body = [&]() -> int {
+    GPK_HIP(hipMemcpyAsync(dZ, Z, (size_t)M * d * 8, hipMemcpyHostToDevice, s));
+    for (gpk_model* m : job.ms) {
+      GPK_TRY(decode_hyp(log_hyp, d, 0.0, m));
+      m->has_y = true;
+      GPK_HIP(hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s));
+      GPK_HIP(hipMemsetAsync(m->dy, 0, (size_t)m->Npad * 8, s));
+      GPK_HIP(hipMemcpyAsync(m->dy, y, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    }
+    GPK_TRY(fit_group(job.ms.data(), P));
+    std::vector<double*> hm(P), hv(P);
+    for (int r = 0; r < P; ++r) {
+      nlml_out[r] = job.ms[r]->nlml;
+      hm[r] = mean_out + (size_t)r * M;
+      hv[r] = var_out + (size_t)r * M;
+    }
+    return predict_group(job.ms.data(), P, dZ, M, hm.data(), hv.data());
+  };
+  int rc = body();
+  if (rc) (void)hipStreamSynchronize(s);
+  dev_free(dZ, (size_t)M * d * 8);
   return rc;
 }
 

@@ -44,6 +44,7 @@ struct Runtime {
   int test_gemm_k1 = 0;   // gpk_test_gemm_nt: split K at this column into two separately stored operands
   int pair_update = 1;    // two panels per trailing update (K doubled) for the far region: 0 never, 1 for Npad <= 8192, 2 always
   int pipe_interleave = 0;  // 1: host submits panel p's substitutions right after panel p (0: after the whole factorisation)
+  int solve_gemm_above = 8;  // gpk_solve: more right-hand sides than this go through the blocked GEMM substitutions
   int fuse_predict = 1;  // bench / compute_prediction: overlap the prediction solve with the factorisation tail
   int xcd_sq = 1;              // XCD-aware 8x8-tile square order in the big GEMMs
   int ncu = 256;         // CUs available to the GEMM streams
@@ -53,7 +54,7 @@ struct Runtime {
   void* nccl = nullptr;
   std::map<std::string, StageTimer> timers;
   std::vector<hipEvent_t> ev_free;
-  std::vector<hipEvent_t> ev_pool;  // dependency events of the look-ahead schedule
+  std::vector<hipEvent_t> ev_dep_free;  // recycled dependency events (timing disabled) of destroyed models
 };
 extern Runtime G;
 
@@ -74,6 +75,14 @@ struct gpk_model {
   int P = 1, r = 0, nloc = 0;
   long ldk = 0;
   bool virtual_rank = false;  // single-process emulation of rank r of P (tests): no RCCL calls
+  // virtual ranks only: the P rank models of the emulated job, indexed by rank.  The "broadcast" / "all-gather" of a
+  // virtual rank is a device copy from the peer's buffers; everything else is the code a real rank runs.
+  gpk_model* const* vgroup = nullptr;
+  // dependency events of the look-ahead schedules, owned by the model (P virtual ranks in one process must not
+  // share them); see model_events()
+  std::vector<hipEvent_t> ev;
+  size_t dws_bytes = 0;       // size dws was allocated with (the nb_big option may change while the handle lives)
+  double* shard_loc = nullptr;  // this rank's slice of a sharded prediction: [mean(Mpad) | var(Mpad)] (peers copy from it)
   std::vector<int> pc0, pw;
   std::vector<size_t> poff;
   size_t L_elems = 0;
@@ -99,9 +108,16 @@ struct FusedPredict {
   double *dR, *dV, *dmean, *dvar;
 };
 int fit_device(gpk_model* m, const FusedPredict* fp = nullptr);  // K build + potrf + w + scalars (inputs resident)
-extern int g_potrf_lookahead_used;  // 1 if the last potrf_device recorded per-panel events in G.ev_pool[0..nP)
+extern int g_potrf_lookahead_used;  // 1 if the last potrf_device recorded per-panel events in m->ev[0..nP)
+extern int g_dist_lookahead_used;   // 1 if the last block-cyclic factorisation ran the look-ahead schedule
 int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel = nullptr);                                 // dK -> dL, dDinv
-int ensure_ev_pool(int n);                                      // dependency events of the look-ahead schedules
+int model_events(gpk_model* m, int n);                         // at least n dependency events in m->ev
+// Block-cyclic (P > 1) entry points work on the LOCAL rank models of one job: a real rank passes itself (n = 1,
+// peers are other processes, exchange = RCCL), the single-process test harness passes all P virtual ranks
+// (exchange = device copies).  Same schedule, same code.
+int potrf_group(gpk_model* const* ms, int n);
+int fit_group(gpk_model* const* ms, int n);
+int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var);
 int build_K(gpk_model* m);                                      // dX -> dK (local block columns)
 int factor_panel(gpk_model* m, int p, hipStream_t s);          // owner only
 int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hipStream_t s);
@@ -114,6 +130,8 @@ int predict_sharded(gpk_model* m, const double* dZ, int M, double* h_mean, doubl
 int nlml_grad_device(gpk_model* m, double* h_grad);
 int potrf_forward(gpk_model* m, double* v);                   // dK -> dL, v <- L^-1 v (pipelined)
 int rows_forward_solve(gpk_model* m, int Mpad, double* dR, double* dV);
+int rows_backward_prepare(gpk_model* m, double* dU, double* dDinvT, hipStream_t s);  // U = L^T, transposed Dinv tiles
+int rows_backward_solve(gpk_model* m, int Mpad, double* dR, double* dY, const double* dU, const double* dDinvT);
 int trsv_forward(gpk_model* m, double* v);                      // v <- L^-1 v  (Npad vector)
 int trsv_backward(gpk_model* m, double* v);                     // v <- L^-T v
 int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, double* dV, double* dmean, double* dvar);

@@ -178,7 +178,8 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r) {
   rc |= dev_alloc_t(&m->dL, m->L_elems);
   rc |= dev_alloc_t(&m->dDinv, (size_t)m->nT * 128 * 128);
   rc |= dev_alloc_t(&m->dscal, 8);
-  rc |= dev_alloc_t(&m->dws, (size_t)64 * std::max(nb, G.nb_big));
+  m->dws_bytes = (size_t)64 * std::max(nb, G.nb_big) * 8;
+  rc |= dev_alloc(reinterpret_cast<void**>(&m->dws), m->dws_bytes);
   rc |= dev_alloc_t(&m->dinfo, 4);
   if (rc) {
     model_destroy(m);
@@ -199,8 +200,9 @@ void model_destroy(gpk_model* m) {
   dev_free(m->dL, m->L_elems * 8);
   dev_free(m->dDinv, (size_t)m->nT * 128 * 128 * 8);
   dev_free(m->dscal, 64);
-  dev_free(m->dws, (size_t)64 * std::max(m->NB, G.nb_big) * 8);
+  dev_free(m->dws, m->dws_bytes);
   dev_free(m->dinfo, 16);
+  for (hipEvent_t e : m->ev) G.ev_dep_free.push_back(e);
   delete m;
 }
 
@@ -329,19 +331,19 @@ int dist_update(gpk_model* m, int p, int first_block, int nblocks_max, hipStream
   return launch_gemm_nt(g, true, s);
 }
 
-int ensure_ev_pool(int n) {
-  while ((int)G.ev_pool.size() < n) {
+int model_events(gpk_model* m, int n) {
+  while ((int)m->ev.size() < n) {
     hipEvent_t e;
-    GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    G.ev_pool.push_back(e);
+    if (!G.ev_dep_free.empty()) {
+      e = G.ev_dep_free.back();
+      G.ev_dep_free.pop_back();
+    } else {
+      GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    m->ev.push_back(e);
   }
   return 0;
 }
-
-// Right-looking with one panel of look-ahead: while the big SYRK of panel p runs on s_main, the
-// high-priority s_panel stream updates block column p+1 and factors panel p+1, so the latency-bound
-// leaf/panel kernels leave the critical path.
-static int potrf_distributed(gpk_model* m);
 
 // C[r0g:, r0g:] (lower) -= [Lp Lq][Lp Lq]^T for two CONSECUTIVE panels p, q = p+1 in ONE pass over C (K = w_p + w_q):
 // half the C traffic and accumulator hand-overs per flop of two separate updates.  Falls back to two launches when
@@ -376,12 +378,12 @@ static int pair_update(gpk_model* m, int p, int r0g, hipStream_t s) {
 static int potrf_device_paired(gpk_model* m, const std::function<int(int)>* after_panel) {
   hipStream_t sm = G.s_main, sp = G.s_panel;
   const int nP = m->nP, np_ = m->Npad;
-  GPK_TRY(ensure_ev_pool(3 * nP + 6));
+  GPK_TRY(model_events(m, 3 * nP + 6));
   g_potrf_lookahead_used = 1;
-  hipEvent_t* ev_panel = G.ev_pool.data();
-  hipEvent_t* ev_near = G.ev_pool.data() + nP;
-  hipEvent_t* ev_farA = G.ev_pool.data() + 2 * nP + 6;
-  hipEvent_t ev_start = G.ev_pool[2 * nP];
+  hipEvent_t* ev_panel = m->ev.data();
+  hipEvent_t* ev_near = m->ev.data() + nP;
+  hipEvent_t* ev_farA = m->ev.data() + 2 * nP + 6;
+  hipEvent_t ev_start = m->ev[2 * nP];
   auto c = [&](int q) { return q < nP ? m->pc0[q] : np_; };
   auto wd = [&](int q) { return q < nP ? m->pw[q] : 0; };
   GPK_HIP(hipEventRecord(ev_start, sm));
@@ -434,12 +436,19 @@ static int potrf_device_paired(gpk_model* m, const std::function<int(int)>* afte
   return 0;
 }
 
+// Right-looking with one panel of look-ahead: while the big SYRK of panel p runs on s_main, the
+// high-priority s_panel stream updates block column p+1 and factors panel p+1, so the latency-bound
+// leaf/panel kernels leave the critical path.
 int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   hipStream_t sm = G.s_main, sp = G.s_panel;
+  if (m->P > 1) {
+    if (m->virtual_rank) return gpk_set_err(-1, "internal: virtual ranks are factored as a group (potrf_group)");
+    gpk_model* one = m;
+    return potrf_group(&one, 1);
+  }
   GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
   const int nP = m->nP;
   g_potrf_lookahead_used = 0;
-  if (m->P > 1) return potrf_distributed(m);
   if (!G.lookahead || nP < 3) {
     for (int p = 0; p < nP; ++p) {
       timer_begin("panel", sm);
@@ -457,11 +466,11 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   // run faster (50 vs 44.5 TFLOP/s) but the three narrow updates per pair it needs (16 % of the flops) cost more
   // than that (N = 16384: 38.1-38.5 vs 36.9-37.05 ms, N = 32768: 241.8 vs 231.9).  1: only up to 8192, 2: always.
   if (nP >= 6 && (G.pair_update == 2 || (G.pair_update == 1 && m->Npad <= 8192))) return potrf_device_paired(m, after_panel);
-  GPK_TRY(ensure_ev_pool(3 * nP + 6));
+  GPK_TRY(model_events(m, 3 * nP + 6));
   g_potrf_lookahead_used = 1;
-  hipEvent_t* ev_panel = G.ev_pool.data();        // panel p factored (recorded on s_panel)
-  hipEvent_t* ev_trail = G.ev_pool.data() + nP;   // rest-update of step p done (recorded on s_main)
-  hipEvent_t ev_start = G.ev_pool[2 * nP];
+  hipEvent_t* ev_panel = m->ev.data();        // panel p factored (recorded on s_panel)
+  hipEvent_t* ev_trail = m->ev.data() + nP;   // rest-update of step p done (recorded on s_main)
+  hipEvent_t ev_start = m->ev[2 * nP];
   // s_panel must not start before the K build queued on s_main has finished
   GPK_HIP(hipEventRecord(ev_start, sm));
   GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
@@ -505,12 +514,25 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
 // every rank updates the block columns it owns.  Look-ahead: the owner of panel p+1 updates THAT block
 // column first, factors it and starts its broadcast on the panel stream while all ranks run the rest
 // of update p on the main stream.
+//
+// The schedule is written as per-rank phases (dist_*_phase) driven by potrf_group over the rank models that live
+// in this process: one for a real rank, all P for the single-process harness of the tests, whose "broadcast" is a
+// device copy from the owner's model.  Both run the very same phases in the same order.
 static int bcast_panel(gpk_model* m, int p, hipStream_t s) {
-  if (m->virtual_rank) return 0;  // the emulation harness copies panels between its rank models
-  const int c0 = m->pc0[p], w = m->pw[p];
+  const int c0 = m->pc0[p], w = m->pw[p], owner = p % m->P;
   const size_t cnt = (size_t)(m->Npad - c0) * w;
-  GPK_TRY(comm_bcast(m->Lpanel(p), cnt, p % m->P, s));
-  GPK_TRY(comm_bcast(m->dDinv + (size_t)(c0 / 128) * 128 * 128, (size_t)(w / 128) * 128 * 128, p % m->P, s));
+  const size_t dcnt = (size_t)(w / 128) * 128 * 128;
+  double* dinv = m->dDinv + (size_t)(c0 / 128) * 128 * 128;
+  if (m->virtual_rank) {
+    if (!m->vgroup) return gpk_set_err(-1, "internal: virtual rank %d without a group", m->r);
+    if (owner == m->r) return 0;
+    const gpk_model* o = m->vgroup[owner];  // the owner's phase was queued on this stream before ours (potrf_group)
+    GPK_HIP(hipMemcpyAsync(m->Lpanel(p), o->Lpanel(p), cnt * 8, hipMemcpyDeviceToDevice, s));
+    GPK_HIP(hipMemcpyAsync(dinv, o->dDinv + (size_t)(c0 / 128) * 128 * 128, dcnt * 8, hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
+  GPK_TRY(comm_bcast(m->Lpanel(p), cnt, owner, s));
+  GPK_TRY(comm_bcast(dinv, dcnt, owner, s));
   return 0;
 }
 static double dist_update_flops(const gpk_model* m, int p, int first_block, int nblocks_max) {
@@ -525,48 +547,109 @@ static double dist_update_flops(const gpk_model* m, int p, int first_block, int 
 static inline int first_local_block_after(const gpk_model* m, int p) {  // # local blocks with global index <= p
   return (p >= m->r) ? (p - m->r) / m->P + 1 : 0;
 }
+static inline bool dist_lookahead(const gpk_model* m) { return G.lookahead && m->nP >= 3; }
 
-static int potrf_distributed(gpk_model* m) {
+// ---- look-ahead schedule, one rank.  Events: ev[p] = panel p available on this rank (s_panel),
+//      ev[nP + p] = rest-update of step p done (s_main), ev[2 nP] = start.
+static int dist_la_begin(gpk_model* m) {
   hipStream_t sm = G.s_main, sp = G.s_panel;
-  const int nP = m->nP, P = m->P, r = m->r;
-  if (!G.lookahead || nP < 3 || m->virtual_rank) {
+  const int nP = m->nP;
+  GPK_TRY(model_events(m, 3 * nP + 6));
+  GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
+  GPK_HIP(hipEventRecord(m->ev[2 * nP], sm));  // s_panel must not start before the K build queued on s_main
+  GPK_HIP(hipStreamWaitEvent(sp, m->ev[2 * nP], 0));
+  if (0 % m->P == m->r) GPK_TRY(factor_panel(m, 0, sp));
+  GPK_TRY(bcast_panel(m, 0, sp));
+  GPK_HIP(hipEventRecord(m->ev[0], sp));
+  return 0;
+}
+// panel phase of step p (s_panel): panel p+1 becomes available on this rank
+static int dist_la_panel_phase(gpk_model* m, int p) {
+  hipStream_t sp = G.s_panel;
+  const int nP = m->nP;
+  if (p + 1 >= nP) return 0;
+  hipEvent_t* ev_panel = m->ev.data();
+  hipEvent_t* ev_trail = m->ev.data() + nP;
+  if ((p + 1) % m->P == m->r) {  // block column p+1 is my local block lg0 (the first one after p)
+    const int lg0 = first_local_block_after(m, p);
+    if (p > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[p - 1], 0));  // its earlier updates ran on s_main
+    GPK_TRY(dist_update(m, p, lg0, 1, sp));
+    GPK_TRY(factor_panel(m, p + 1, sp));
+  }
+  GPK_TRY(bcast_panel(m, p + 1, sp));  // every rank takes part
+  GPK_HIP(hipEventRecord(ev_panel[p + 1], sp));
+  return 0;
+}
+// update phase of step p (s_main): every local block column right of the look-ahead column gets update p
+static int dist_la_update_phase(gpk_model* m, int p) {
+  hipStream_t sm = G.s_main;
+  const int nP = m->nP;
+  hipEvent_t* ev_panel = m->ev.data();
+  hipEvent_t* ev_trail = m->ev.data() + nP;
+  const int lg0 = first_local_block_after(m, p);
+  const bool own_next = (p + 1 < nP) && ((p + 1) % m->P == m->r);
+  GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
+  timer_begin("trailing", sm, dist_update_flops(m, p, lg0 + (own_next ? 1 : 0), 1 << 30));
+  GPK_TRY(dist_update(m, p, lg0 + (own_next ? 1 : 0), 1 << 30, sm));
+  timer_end("trailing", sm);
+  GPK_HIP(hipEventRecord(ev_trail[p], sm));
+  return 0;
+}
+static int dist_la_end(gpk_model* m) {
+  GPK_HIP(hipStreamWaitEvent(G.s_main, m->ev[m->nP - 1], 0));  // everything after potrf runs on s_main
+  return 0;
+}
+// ---- no look-ahead (option lookahead = 0, or fewer than three panels): everything on s_main
+static int dist_plain_panel_phase(gpk_model* m, int p) {
+  hipStream_t sm = G.s_main;
+  if (p == 0) GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
+  if (p % m->P == m->r) GPK_TRY(factor_panel(m, p, sm));
+  return bcast_panel(m, p, sm);
+}
+static int dist_plain_update_phase(gpk_model* m, int p) {
+  hipStream_t sm = G.s_main;
+  const int lg0 = first_local_block_after(m, p);
+  timer_begin("trailing", sm, dist_update_flops(m, p, lg0, 1 << 30));
+  GPK_TRY(dist_update(m, p, lg0, 1 << 30, sm));
+  timer_end("trailing", sm);
+  return 0;
+}
+
+int g_dist_lookahead_used = 0;
+
+// ms[0..n): the rank models of ONE block-cyclic factorisation that live in this process (n = 1: a real rank,
+// n = P: every virtual rank, in rank order).  Within a phase the owner of the panel being produced goes first,
+// so that in the single-process harness the owner's factor kernels precede the peers' copies in stream order.
+int potrf_group(gpk_model* const* ms, int n) {
+  if (n < 1 || !ms || !ms[0]) return gpk_set_err(-1, "potrf_group: empty group");
+  const int nP = ms[0]->nP, P = ms[0]->P;
+  for (int i = 0; i < n; ++i) {
+    const gpk_model* m = ms[i];
+    if (m->P != P || m->nP != nP || m->Npad != ms[0]->Npad)
+      return gpk_set_err(-1, "potrf_group: rank models disagree on the block-cyclic layout");
+    if (n > 1 && (!m->virtual_rank || n != P || m->r != i || m->vgroup != ms))
+      return gpk_set_err(-1, "potrf_group: a group of %d needs the %d virtual ranks in rank order", n, P);
+  }
+  auto from_owner = [&](int owner, const std::function<int(gpk_model*)>& f) -> int {
+    for (int k = 0; k < n; ++k) GPK_TRY(f(ms[n == 1 ? 0 : (owner + k) % n]));
+    return 0;
+  };
+  g_potrf_lookahead_used = 0;
+  const bool la = dist_lookahead(ms[0]);
+  g_dist_lookahead_used = la ? 1 : 0;
+  if (!la) {
     for (int p = 0; p < nP; ++p) {
-      if (p % P == r) GPK_TRY(factor_panel(m, p, sm));
-      GPK_TRY(bcast_panel(m, p, sm));
-      timer_begin("trailing", sm, dist_update_flops(m, p, first_local_block_after(m, p), 1 << 30));
-      GPK_TRY(dist_update(m, p, first_local_block_after(m, p), 1 << 30, sm));
-      timer_end("trailing", sm);
+      GPK_TRY(from_owner(p % P, [&](gpk_model* m) { return dist_plain_panel_phase(m, p); }));
+      GPK_TRY(from_owner(0, [&](gpk_model* m) { return dist_plain_update_phase(m, p); }));
     }
     return 0;
   }
-  GPK_TRY(ensure_ev_pool(3 * nP + 6));
-  hipEvent_t* ev_panel = G.ev_pool.data();       // panel p available on this rank (recorded on s_panel)
-  hipEvent_t* ev_trail = G.ev_pool.data() + nP;  // rest-update of step p done (recorded on s_main)
-  hipEvent_t ev_start = G.ev_pool[2 * nP];
-  GPK_HIP(hipEventRecord(ev_start, sm));
-  GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
-  if (0 % P == r) GPK_TRY(factor_panel(m, 0, sp));
-  GPK_TRY(bcast_panel(m, 0, sp));
-  GPK_HIP(hipEventRecord(ev_panel[0], sp));
+  GPK_TRY(from_owner(0, [&](gpk_model* m) { return dist_la_begin(m); }));
   for (int p = 0; p < nP; ++p) {
-    const int lg0 = first_local_block_after(m, p);
-    const bool own_next = (p + 1 < nP) && ((p + 1) % P == r);
-    if (p + 1 < nP) {
-      if (own_next) {  // block column p+1 is my local block lg0 (the first one after p)
-        if (p > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[p - 1], 0));  // its earlier updates ran on s_main
-        GPK_TRY(dist_update(m, p, lg0, 1, sp));
-        GPK_TRY(factor_panel(m, p + 1, sp));
-      }
-      GPK_TRY(bcast_panel(m, p + 1, sp));  // every rank takes part; ordered after update p-1 on all ranks
-      GPK_HIP(hipEventRecord(ev_panel[p + 1], sp));
-    }
-    GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
-    timer_begin("trailing", sm, dist_update_flops(m, p, lg0 + (own_next ? 1 : 0), 1 << 30));
-    GPK_TRY(dist_update(m, p, lg0 + (own_next ? 1 : 0), 1 << 30, sm));
-    timer_end("trailing", sm);
-    GPK_HIP(hipEventRecord(ev_trail[p], sm));
+    GPK_TRY(from_owner((p + 1) % P, [&](gpk_model* m) { return dist_la_panel_phase(m, p); }));
+    GPK_TRY(from_owner(0, [&](gpk_model* m) { return dist_la_update_phase(m, p); }));
   }
-  GPK_HIP(hipStreamWaitEvent(sm, ev_panel[nP - 1], 0));
+  GPK_TRY(from_owner(0, [&](gpk_model* m) { return dist_la_end(m); }));
   return 0;
 }
 
@@ -620,13 +703,13 @@ int potrf_forward(gpk_model* m, double* v) {
     GPK_TRY(potrf_device(m));
     return trsv_forward(m, v);
   }
-  GPK_TRY(ensure_ev_pool(3 * m->nP + 6));
-  hipEvent_t ev_in = G.ev_pool[2 * m->nP + 2];
+  GPK_TRY(model_events(m, 3 * m->nP + 6));
+  hipEvent_t ev_in = m->ev[2 * m->nP + 2];
   GPK_HIP(hipEventRecord(ev_in, s));  // v and dK are produced on s_main
   GPK_HIP(hipStreamWaitEvent(sq, ev_in, 0));
   GPK_TRY(potrf_device(m));
   if (!g_potrf_lookahead_used) return trsv_forward(m, v);
-  hipEvent_t* ev_panel = G.ev_pool.data();
+  hipEvent_t* ev_panel = m->ev.data();
   const int np_ = m->Npad;
   for (int p = 0; p < m->nP; ++p) {
     const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
@@ -635,7 +718,7 @@ int potrf_forward(gpk_model* m, double* v) {
     GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, v + c0, 0, sq));
     GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, v + c0, v + c0 + w, sq));
   }
-  hipEvent_t ev_out = G.ev_pool[2 * m->nP + 3];
+  hipEvent_t ev_out = m->ev[2 * m->nP + 3];
   GPK_HIP(hipEventRecord(ev_out, sq));
   GPK_HIP(hipStreamWaitEvent(s, ev_out, 0));
   return 0;
@@ -645,9 +728,66 @@ int potrf_forward(gpk_model* m, double* v) {
 static int predict_diag(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s);
 static int predict_update(gpk_model* m, int p, int Mpad, int cg0, int ncols, double* dR, double* dV, hipStream_t s);
 
+// Block-cyclic fit of the rank models living in this process (see potrf_group): every rank builds its block columns
+// of K, the group factors, every rank then holds all of L and runs the y substitution redundantly.
+int fit_group(gpk_model* const* ms, int n) {
+  hipStream_t s = G.s_main;
+  for (int i = 0; i < n; ++i) {
+    gpk_model* m = ms[i];
+    timer_begin("kbuild", s, 4.0 * m->Npad * (double)m->ldk + 8.0 * m->N * m->d);
+    GPK_TRY(build_K(m));
+    timer_end("kbuild", s);
+  }
+  timer_begin("potrf", s);
+  GPK_TRY(potrf_group(ms, n));
+  timer_end("potrf", s);
+  for (int i = 0; i < n; ++i) {
+    gpk_model* m = ms[i];
+    GPK_TRY(launch_sum_log_diag(m->dDinv, m->N, m->dscal + 0, s));
+    if (m->has_y) {
+      timer_begin("solve_y", s);
+      GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)m->Npad * 8, hipMemcpyDeviceToDevice, s));
+      GPK_TRY(trsv_forward(m, m->dw));
+      GPK_TRY(launch_dot(m->dw, m->dw, m->Npad, m->dscal + 1, s));
+      timer_end("solve_y", s);
+    }
+  }
+  std::vector<double> hs((size_t)2 * n, 0.0);
+  std::vector<int> hinfo(n, 0);
+  for (int i = 0; i < n; ++i) {
+    GPK_HIP(hipMemcpyAsync(&hs[2 * i], ms[i]->dscal, 16, hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipMemcpyAsync(&hinfo[i], ms[i]->dinfo, 4, hipMemcpyDeviceToHost, s));
+  }
+  GPK_HIP(hipStreamSynchronize(s));
+  // only the owner of the failing panel saw the pivot: the verdict is the maximum over all ranks
+  int worst = 0;
+  for (int i = 0; i < n; ++i) worst = std::max(worst, hinfo[i]);
+  if (!ms[0]->virtual_rank && ms[0]->P > 1) {
+    double hi = (double)worst;
+    GPK_TRY(gpk_comm_allreduce_max(&hi, 1));
+    worst = (int)hi;
+  }
+  for (int i = 0; i < n; ++i) {
+    gpk_model* m = ms[i];
+    m->info = worst;
+    if (worst > 0) continue;
+    m->logdet = hs[2 * i];
+    m->quad = m->has_y ? hs[2 * i + 1] : 0.0;
+    m->nlml = m->has_y ? 0.5 * m->quad + m->logdet + 0.5 * m->N * std::log(2.0 * M_PI) : m->logdet;  // GPr.py:64-69
+  }
+  if (worst > 0) return worst > ms[0]->N ? ms[0]->N : worst;
+  return 0;
+}
+
 int fit_device(gpk_model* m, const FusedPredict* fp) {
   hipStream_t s = G.s_main;
   const int np_ = m->Npad;
+  if (m->P > 1) {
+    if (fp) return gpk_set_err(-1, "internal: fused prediction on a block-cyclic model");
+    if (m->virtual_rank) return gpk_set_err(-1, "internal: virtual ranks are fitted as a group (fit_group)");
+    gpk_model* one = m;
+    return fit_group(&one, 1);
+  }
   timer_begin("kbuild", s, (m->keep_k ? 8.0 : 4.0) * np_ * np_ + 8.0 * m->N * m->d);
   GPK_TRY(build_K(m));
   timer_end("kbuild", s);
@@ -658,8 +798,8 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   const bool fuse = fp && G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3;
   if (G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3 && (fuse || m->has_y)) {
     // s_pred may start once K is built (Kzx only needs X, the y substitution only panels and y)
-    GPK_TRY(ensure_ev_pool(3 * m->nP + 6));
-    ev_kb = G.ev_pool[2 * m->nP + 2];
+    GPK_TRY(model_events(m, 3 * m->nP + 6));
+    ev_kb = m->ev[2 * m->nP + 2];
     GPK_HIP(hipEventRecord(ev_kb, s));
   }
   // Everything that only needs panels <= p goes to s_pred behind the per-panel events of the
@@ -673,7 +813,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   hipStream_t sq = G.s_pred;
   hipStream_t sy = sq;  // one stream for both substitutions (see gpk_init on the stream count)
   std::function<int(int)> hook = [&](int p) -> int {
-    hipEvent_t* ev_panel = G.ev_pool.data();
+    hipEvent_t* ev_panel = m->ev.data();
     const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
     if (m->has_y) {
       double* Lp = m->Lpanel(p);
@@ -717,11 +857,11 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
       timer_end("predict", sq);
       fused_done = true;
     }
-    hipEvent_t ev_pd = G.ev_pool[2 * m->nP + 3];
+    hipEvent_t ev_pd = m->ev[2 * m->nP + 3];
     GPK_HIP(hipEventRecord(ev_pd, sq));
     GPK_HIP(hipStreamWaitEvent(s, ev_pd, 0));
     if (sy != sq) {
-      hipEvent_t ev_yd = G.ev_pool[2 * m->nP + 4];
+      hipEvent_t ev_yd = m->ev[2 * m->nP + 4];
       GPK_HIP(hipEventRecord(ev_yd, sy));
       GPK_HIP(hipStreamWaitEvent(s, ev_yd, 0));
     }
@@ -750,11 +890,6 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   GPK_HIP(hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s));
   if (G.stamps && G.dstamps) GPK_HIP(hipMemcpyAsync(G.hstamps.data(), G.dstamps, 1024 * 8, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipStreamSynchronize(s));
-  if (m->P > 1 && !m->virtual_rank) {  // only the owner of the failing panel saw it
-    double hi = (double)hinfo;
-    GPK_TRY(gpk_comm_allreduce_max(&hi, 1));
-    hinfo = (int)hi;
-  }
   m->info = hinfo;
   if (hinfo > 0) return hinfo > m->N ? m->N : hinfo;
   m->logdet = hs[0];
@@ -819,10 +954,10 @@ int rows_forward_solve(gpk_model* m, int Mpad, double* dR, double* dV) {
   } else {
     // one panel of look-ahead, as in the factorisation: the latency-bound diagonal solves of panel p+1 run on
     // s_panel while the wide update of panel p runs on s_main.
-    GPK_TRY(ensure_ev_pool(3 * nP + 6));
-    hipEvent_t* ev_diag = G.ev_pool.data();
-    hipEvent_t* ev_upd = G.ev_pool.data() + nP;
-    hipEvent_t ev_start = G.ev_pool[2 * nP];
+    GPK_TRY(model_events(m, 3 * nP + 6));
+    hipEvent_t* ev_diag = m->ev.data();
+    hipEvent_t* ev_upd = m->ev.data() + nP;
+    hipEvent_t ev_start = m->ev[2 * nP];
     GPK_HIP(hipEventRecord(ev_start, sm));
     GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
     GPK_TRY(predict_diag(m, 0, Mpad, dR, dV, sp));
@@ -841,6 +976,57 @@ int rows_forward_solve(gpk_model* m, int Mpad, double* dR, double* dV) {
       GPK_HIP(hipEventRecord(ev_upd[p], sm));
     }
     GPK_HIP(hipStreamWaitEvent(sm, ev_diag[nP - 1], 0));
+  }
+  return 0;
+}
+
+// Y = R L^-1 for Mpad rows (the mirror of rows_forward_solve; together they apply K^-1 = L^-T L^-1 to many
+// right-hand sides on the MFMA GEMM: gpk_solve, the replacement of the explicit iK of GPr.py:63 / GPpref.py:129).
+// The products are R . L ("NN"), the kernel is NT, so the caller supplies U = L^T as a dense Npad x Npad array
+// (only U[j, k >= block of j] is read; rows_backward_prepare fills it panel by panel) and the transposed inverted
+// diagonal tiles DinvT (128 x nT*128: DinvT[j][t*128 + k] = Dinv_t[k][j]).  Right-looking from the last panel:
+//   Y[:, p] = R[:, p] Lpp^-1 (sub-blocks last to first),   R[:, 0:c0] -= Y[:, p] U[0:c0, p]^T   (one GEMM, K = w).
+int rows_backward_prepare(gpk_model* m, double* dU, double* dDinvT, hipStream_t s) {
+  const int np_ = m->Npad;
+  for (int p = 0; p < m->nP; ++p) {
+    const int c0 = m->pc0[p], w = m->pw[p];
+    GPK_TRY(launch_transpose(m->Lpanel(p), w, np_ - c0, w, dU + (long)c0 * np_ + c0, np_, s));
+  }
+  return launch_transpose(m->dDinv, 128, m->nT * 128, 128, dDinvT, (long)m->nT * 128, s);
+}
+int rows_backward_solve(gpk_model* m, int Mpad, double* dR, double* dY, const double* dU, const double* dDinvT) {
+  hipStream_t s = G.s_main;
+  const int np_ = m->Npad;
+  const long ldd = (long)m->nT * 128;
+  for (int p = m->nP - 1; p >= 0; --p) {
+    const int c0 = m->pc0[p], w = m->pw[p];
+    for (int sb = w / 128 - 1; sb >= 0; --sb) {
+      const int cs = c0 + sb * 128;
+      const int after = c0 + w - cs - 128;  // columns of this panel right of the sub-block, already solved
+      if (after > 0) {
+        GemmNT g{};
+        g.A = dY + cs + 128; g.lda = np_;
+        g.B = dU + (long)cs * np_ + cs + 128; g.ldb = np_;
+        g.C = dR + cs; g.ldc = np_;
+        g.m = Mpad; g.n = 128; g.k = after; g.sub = 1;
+        GPK_TRY(launch_gemm_nt(g, false, s));
+      }
+      GemmNT g{};
+      g.A = dR + cs; g.lda = np_;
+      g.B = dDinvT + (long)(cs / 128) * 128; g.ldb = ldd;
+      g.C = dY + cs; g.ldc = np_;
+      g.m = Mpad; g.n = 128; g.k = 128; g.sub = 0;
+      GPK_TRY(launch_gemm_nt(g, false, s));
+    }
+    if (c0 > 0) {
+      GemmNT g{};
+      g.A = dY + c0; g.lda = np_;
+      g.B = dU + c0; g.ldb = np_;
+      g.C = dR; g.ldc = np_;
+      g.m = Mpad; g.n = c0; g.k = w; g.sub = 1;
+      if ((long)(Mpad / 128) * (c0 / 128) < G.pred_small_below) GPK_TRY(launch_gemm_nt(g, false, s));
+      else GPK_TRY(launch_gemm_auto(g, s));
+    }
   }
   return 0;
 }
@@ -930,52 +1116,76 @@ int nlml_grad_device(gpk_model* m, double* h_grad) {
 }
 
 // ------------------------------------------------------------------ prediction entry shared by gpk_predict / bench
-int predict_sharded(gpk_model* m, const double* dZ, int M, double* h_mean, double* h_var) {
+// M test points sharded over the P ranks of a block-cyclic model (every rank holds all of L): rank q solves the
+// points [q Mc, (q+1) Mc), the [mean | var] slices are all-gathered.  ms[0..n) as in potrf_group; every local rank
+// writes the gathered result to its own h_mean[i] / h_var[i].
+int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var) {
   hipStream_t s = G.s_main;
-  const int P = (m->P > 1 && !m->virtual_rank) ? m->P : 1;
-  const int Mc = (M + P - 1) / P;             // test points per rank
-  const int m0 = (P > 1) ? m->r * Mc : 0;
-  int cnt = M - m0;
-  if (cnt > Mc) cnt = Mc;
-  if (cnt < 0) cnt = 0;
+  if (n < 1 || !ms || !ms[0]) return gpk_set_err(-1, "predict_group: empty group");
+  const int P = ms[0]->P, d = ms[0]->d;
+  if (n > 1 && n != P) return gpk_set_err(-1, "predict_group: a group of %d needs the %d virtual ranks", n, P);
+  const int Mc = (M + P - 1) / P;  // test points per rank
   const int Mpad = round_up(Mc, 128);
-  const size_t szR = (size_t)Mpad * m->Npad;
-  double *dR = nullptr, *dV = nullptr, *dloc = nullptr, *dall = nullptr;
+  const size_t szR = (size_t)Mpad * ms[0]->Npad, slice = (size_t)2 * Mpad;
+  struct Bufs { double *dR = nullptr, *dV = nullptr, *dall = nullptr; };
+  std::vector<Bufs> bufs(n);
+  std::vector<std::vector<double>> hall(n, std::vector<double>(slice * P));
   int rc = 0;
-  rc |= dev_alloc_t(&dR, szR);
-  rc |= dev_alloc_t(&dV, szR);
-  rc |= dev_alloc_t(&dloc, (size_t)2 * Mpad);
-  rc |= dev_alloc_t(&dall, (size_t)2 * Mpad * P);
-  std::vector<double> hall((size_t)2 * Mpad * P);
-  if (!rc) {
-    do {
-      if (hipMemsetAsync(dloc, 0, (size_t)2 * Mpad * 8, s) != hipSuccess) { rc = gpk_set_err(-2, "memset failed"); break; }
-      if (cnt > 0) {
-        rc = predict_device(m, dZ + (size_t)m0 * m->d, cnt, round_up(cnt, 128), dR, dV, dloc, dloc + Mpad);
-        if (rc) break;
+  for (int i = 0; i < n && !rc; ++i) {
+    rc |= dev_alloc_t(&bufs[i].dR, szR);
+    rc |= dev_alloc_t(&bufs[i].dV, szR);
+    rc |= dev_alloc_t(&ms[i]->shard_loc, slice);
+    rc |= dev_alloc_t(&bufs[i].dall, slice * P);
+  }
+  auto body = [&]() -> int {
+    for (int i = 0; i < n; ++i) {  // local solve of this rank's slice
+      gpk_model* m = ms[i];
+      const int m0 = (P > 1) ? m->r * Mc : 0;
+      const int cnt = std::max(0, std::min(Mc, M - m0));
+      GPK_HIP(hipMemsetAsync(m->shard_loc, 0, slice * 8, s));
+      if (cnt > 0)
+        GPK_TRY(predict_device(m, dZ + (size_t)m0 * d, cnt, round_up(cnt, 128), bufs[i].dR, bufs[i].dV, m->shard_loc,
+                               m->shard_loc + Mpad));
+    }
+    for (int i = 0; i < n; ++i) {  // all-gather of the slices
+      gpk_model* m = ms[i];
+      if (P == 1) {
+        GPK_HIP(hipMemcpyAsync(bufs[i].dall, m->shard_loc, slice * 8, hipMemcpyDeviceToDevice, s));
+      } else if (m->virtual_rank) {
+        if (!m->vgroup) return gpk_set_err(-1, "internal: virtual rank %d without a group", m->r);
+        for (int q = 0; q < P; ++q)
+          GPK_HIP(hipMemcpyAsync(bufs[i].dall + slice * q, m->vgroup[q]->shard_loc, slice * 8, hipMemcpyDeviceToDevice, s));
+      } else {
+        GPK_TRY(comm_allgather(m->shard_loc, bufs[i].dall, slice, s));
       }
-      const double* src = dloc;
-      if (P > 1) {
-        rc = comm_allgather(dloc, dall, (size_t)2 * Mpad, s);
-        if (rc) break;
-        src = dall;
-      }
-      if (hipMemcpyAsync(hall.data(), src, (size_t)2 * Mpad * P * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-      if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "predict: %s", hipGetErrorString(hipGetLastError())); break; }
+      GPK_HIP(hipMemcpyAsync(hall[i].data(), bufs[i].dall, slice * P * 8, hipMemcpyDeviceToHost, s));
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return gpk_set_err(-2, "predict: %s", hipGetErrorString(hipGetLastError()));
+    for (int i = 0; i < n; ++i)
       for (int q = 0; q < P; ++q) {
         const int q0 = q * Mc;
-        int qc = M - q0;
-        if (qc > Mc) qc = Mc;
-        for (int i = 0; i < qc; ++i) {
-          h_mean[q0 + i] = hall[(size_t)q * 2 * Mpad + i];
-          h_var[q0 + i] = hall[(size_t)q * 2 * Mpad + Mpad + i];
+        const int qc = std::min(Mc, M - q0);
+        for (int j = 0; j < qc; ++j) {
+          h_mean[i][q0 + j] = hall[i][slice * q + j];
+          h_var[i][q0 + j] = hall[i][slice * q + Mpad + j];
         }
       }
-    } while (0);
+    return 0;
+  };
+  if (!rc) rc = body();
+  if (rc) (void)hipStreamSynchronize(s);
+  for (int i = 0; i < n; ++i) {
+    if (bufs[i].dR) dev_free(bufs[i].dR, szR * 8);
+    if (bufs[i].dV) dev_free(bufs[i].dV, szR * 8);
+    if (bufs[i].dall) dev_free(bufs[i].dall, slice * P * 8);
+    if (ms[i]->shard_loc) dev_free(ms[i]->shard_loc, slice * 8);
+    ms[i]->shard_loc = nullptr;
   }
-  if (dR) dev_free(dR, szR * 8);
-  if (dV) dev_free(dV, szR * 8);
-  if (dloc) dev_free(dloc, (size_t)2 * Mpad * 8);
-  if (dall) dev_free(dall, (size_t)2 * Mpad * P * 8);
   return rc;
+}
+
+int predict_sharded(gpk_model* m, const double* dZ, int M, double* h_mean, double* h_var) {
+  if (m->virtual_rank && m->P > 1) return gpk_set_err(-1, "internal: virtual ranks predict as a group (predict_group)");
+  gpk_model* one = m;
+  return predict_group(&one, 1, dZ, M, &h_mean, &h_var);
 }

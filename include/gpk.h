@@ -41,7 +41,9 @@ double      gpk_get_option(const char* key);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */
 /* rank 0 calls gpk_comm_unique_id, the host broadcasts the 128 bytes by any
- * means (bench.py: torch.distributed/gloo), every rank calls gpk_comm_init.  */
+ * means (gptest_amd/dist.py: a plain TCP socket next to MASTER_PORT), every rank
+ * calls gpk_comm_init.  A multi-rank process gives up the substitution stream
+ * of the single-GPU pipeline (block-cyclic models never use it).            */
 int gpk_comm_unique_id(void* out128);
 int gpk_comm_init(int rank, int nranks, const void* uid128);
 int gpk_comm_rank(void);
@@ -130,13 +132,19 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
 /* ---- kernel-level test hooks (tests/ only; host buffers, row-major) --------- */
 /* C (m x n) = [C -] A (m x k) * B (n x k)^T through the MFMA kernel; tile = 128 or 64. */
 int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile);
-/* single-GPU emulation of the P-rank block-cyclic Cholesky (RCCL broadcast replaced by D2D copies). */
 /* the RCCL calls of the multi-rank path (broadcast on the panel stream, all-gather and all-reduce on the update
  * stream) on a one-rank communicator, payload checked: what a 1-GPU box can verify of gpk_comm.hip. */
 int gpk_test_rccl_selfcheck(int n_doubles);
+/* single-GPU emulation of the P-rank block-cyclic Cholesky: P virtual rank models driven through the production
+ * schedule (potrf_group: per-rank panel / update phases on the panel and update streams, look-ahead), with the
+ * RCCL broadcast replaced by device copies from the owner's model.  P = 1: the production one-GPU factorisation. */
 int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out);
 /* same emulation, every virtual rank builds its own block columns of K(X,X) on the device first. */
 int gpk_test_dist_fit(const double* X, int N, int d, const double* log_hyp, double jitter, int P, double* L_out);
+/* the whole posterior of a P-rank job on P virtual ranks (fit_group + predict_group, all-gather emulated):
+ * nlml_out[P], mean_out / var_out [P][M] = what every rank ends up with. */
+int gpk_test_dist_posterior(const double* X, const double* y, int N, int d, const double* log_hyp, const double* Z,
+                            int M, int P, double* nlml_out, double* mean_out, double* var_out);
 /* device-resident timing of the kernel-matrix builder (mode 0 SE, 1 squared distance, 2 stores only). */
 int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_out);
 /* device-resident timing of the MFMA GEMM: C (m x n) -= A (m x k) B (n x k)^T, `reps` launches; ms per launch. */

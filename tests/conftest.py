@@ -26,3 +26,29 @@ def gpk():
 
 def golden_cases():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("gpr_") and f.endswith(".npz"))
+
+
+# every option gpk_set_option knows, in an order that restores correctly ("nb" switches nb_auto off, so nb_auto
+# comes after it)
+OPTION_KEYS = ["nb", "nb_auto", "nb_big", "nb_big_until", "nb_small", "nb_small_from", "lookahead", "gemm_variant",
+               "xcd_sq", "leaf_direct_rows", "stamps", "pred_small_below", "small_tile_below", "leaf_algo",
+               "test_gemm_k1", "pair_update", "pipe_interleave", "fuse_predict", "timing"]
+
+
+@pytest.fixture(autouse=True)
+def _restore_gpk_options(request):
+    """GPU tests: snapshot every libgpk option before the test and restore all of them afterwards, so that no test
+    can leave another one running a non-default schedule (round-1 advice: 'nb' used to leak nb_auto = 0)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from gptest_amd import _lib
+
+    _lib.init()
+    before = {k: _lib.get_option(k) for k in OPTION_KEYS}
+    assert all(v == v for v in before.values()), before  # no NaN: every key is readable
+    yield
+    for k in OPTION_KEYS:
+        if _lib.get_option(k) != before[k]:
+            _lib.set_option(k, before[k])
+    assert {k: _lib.get_option(k) for k in OPTION_KEYS} == before
