@@ -244,7 +244,7 @@ def main():
     l.gpk_comm_destroy()
     # everything is measured and printed: release the GPU objects explicitly (a profiler attached to this process
     # needs that for a clean exit), but never let the release keep the process alive
-    _lib.shutdown(full=True, watchdog_s=20.0)
+    _lib.shutdown(watchdog_s=20.0)
     if rank == 0 and not parity_ok:
         sys.exit(4)
 

@@ -140,19 +140,17 @@ def init(device=None):
     _inited = True
 
 
-def shutdown(full=True, watchdog_s=None):
-    """Release streams, events and pooled HBM.  ``full=False`` (what the interpreter-exit handler uses) leaves the
-    CU-masked streams to process teardown: their hipStreamDestroy has been seen to hang in one scenario, and an exit
-    handler must never hang.  ``watchdog_s``: run the release on a helper thread; if it has not returned in time the
-    process is ended with exit status 3 (a stuck teardown is a failure and must be visible to whoever launched the
-    script, even though its results are already printed)."""
+def shutdown(watchdog_s=None):
+    """Release streams, events and pooled HBM (gpk_shutdown).  ``watchdog_s``: run the release on a helper thread;
+    if it has not returned in time the process is ended with exit status 3 -- a stuck teardown is a failure and must
+    be visible to whoever launched the script, even though its results are already printed.  (Round 1 saw
+    hipStreamDestroy hang on a CU-masked stream for one destroy order; gpk_shutdown uses the order that does not,
+    scripts/shutdown_probe.py replays both.)"""
     global _inited
     if _lib is None or not _inited:
         _inited = False
         return
     _inited = False
-    if not full:
-        _lib.gpk_set_option(b"shutdown_keep_masked", 1.0)
     if watchdog_s is None:
         _lib.gpk_shutdown()
         return
@@ -170,7 +168,8 @@ def shutdown(full=True, watchdog_s=None):
 
 
 def _shutdown_at_exit():
-    shutdown(full=False)
+    # same full release as an explicit shutdown(); the watchdog turns a stuck teardown into exit status 3
+    shutdown(watchdog_s=30.0)
 
 
 def set_option(key, value):

@@ -157,18 +157,17 @@ void gpk_shutdown(void) {
   timers_reset();
   for (hipEvent_t e : G.ev_free) (void)hipEventDestroy(e);
   G.ev_free.clear();
-  // Order matters: update stream, then substitution stream, then leaf stream hung in the leaf stream's
-  // hipStreamDestroy (process that had only run the leaf kernel on the update stream, 4 of 4 runs); substitution
-  // stream first did not.  The interpreter-exit handler additionally keeps the CU-masked streams alive
-  // (option shutdown_keep_masked) so that no process can hang at exit; explicit shutdown destroys everything,
-  // which a profiler attached to the process needs for its own teardown.
-  const bool destroy_masked = !G.cu_reserved || !G.shutdown_keep_masked;
+  // Destroy order: substitution stream, update stream (CU-masked), optional leaf stream (CU-masked), panel chain.
+  // Round 1 saw hipStreamDestroy of the masked leaf stream hang when the masked update stream and then the
+  // substitution stream had been destroyed before it; GPK_SHUTDOWN_ORDER=old replays that order for
+  // scripts/shutdown_probe.py (diagnosis only).
+  const char* env_order = getenv("GPK_SHUTDOWN_ORDER");
+  const bool old_order = env_order && !strcmp(env_order, "old");
+  if (old_order) SD_STEP("destroy s_main", if (G.s_main) (void)hipStreamDestroy(G.s_main));
   SD_STEP("destroy s_pred", if (G.s_pred && G.s_pred != G.s_panel) (void)hipStreamDestroy(G.s_pred));
   G.s_pred = nullptr;
-  if (destroy_masked) {
-    SD_STEP("destroy s_main", if (G.s_main) (void)hipStreamDestroy(G.s_main));
-    SD_STEP("destroy s_leaf", if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf));
-  }
+  if (!old_order) SD_STEP("destroy s_main", if (G.s_main) (void)hipStreamDestroy(G.s_main));
+  SD_STEP("destroy s_leaf", if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf));
   SD_STEP("destroy s_panel", if (G.s_panel) (void)hipStreamDestroy(G.s_panel));
   SD_STEP("destroy events", {
     for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
@@ -226,8 +225,6 @@ int gpk_set_option(const char* key, double value) {
   } else if (k == "leaf_algo") {
     extern int g_leaf_algo;
     g_leaf_algo = (int)value;
-  } else if (k == "shutdown_keep_masked") {
-    G.shutdown_keep_masked = (int)value;
   } else if (k == "test_gemm_k1") {
     G.test_gemm_k1 = (int)value;
   } else if (k == "pair_update") {

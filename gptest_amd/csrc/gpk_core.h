@@ -40,7 +40,6 @@ struct Runtime {
   std::vector<unsigned long long> hstamps;
   int pred_small_below = 300;  // predict_update: same rule for the substitution GEMMs
   int small_tile_below = 256;  // panel_update: launches with fewer 128x128 tiles than this use the 64x64-tile kernel
-  int shutdown_keep_masked = 0;  // gpk_shutdown leaves the CU-masked streams to process teardown (exit handler)
   int test_gemm_k1 = 0;   // gpk_test_gemm_nt: split K at this column into two separately stored operands
   int pair_update = 1;    // two panels per trailing update (K doubled) for the far region: 0 never, 1 for Npad <= 8192, 2 always
   int pipe_interleave = 0;  // 1: host submits panel p's substitutions right after panel p (0: after the whole factorisation)
