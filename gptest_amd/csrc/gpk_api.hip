@@ -49,11 +49,17 @@ int gpk_init(int device) {
     // Mask bit i <-> XCD (i % 8) when GPK_RESERVE_MODE=0 (default), XCD (i / (ncu/8)) when 1.
     const char* env_mode = getenv("GPK_RESERVE_MODE");
     const int mode = env_mode ? atoi(env_mode) : 0;
-    for (int x = 0; x < 8; ++x) {
-      const int r = (mode == 0) ? (ncu - 8 + x) : ((x + 1) * (ncu / 8) - 1);
-      m_all[r / 32] &= ~(1u << (r % 32));
-      m_leaf[r / 32] |= (1u << (r % 32));
-    }
+    const char* env_rn = getenv("GPK_RESERVE_PER_XCD");  // CUs per XCD kept out of the update stream's mask
+    int per_xcd = env_rn ? atoi(env_rn) : 1;
+    if (per_xcd < 1) per_xcd = 1;
+    if (per_xcd > 16) per_xcd = 16;
+    for (int j = 0; j < per_xcd; ++j)
+      for (int x = 0; x < 8; ++x) {
+        const int r = (mode == 0) ? (ncu - 8 * (j + 1) + x) : ((x + 1) * (ncu / 8) - 1 - j);
+        m_all[r / 32] &= ~(1u << (r % 32));
+        m_leaf[r / 32] |= (1u << (r % 32));
+      }
+    G.ncu_reserved = 8 * per_xcd;
     hipError_t e1 = hipExtStreamCreateWithCUMask(&G.s_main, words, m_all.data());
     // s_panel (the latency-critical panel chain): high PRIORITY instead of a mask -- the two cannot be combined
     // through HIP.  Its skinny GEMMs may also use the reserved CU; a leaf only ever follows them in stream
@@ -109,7 +115,7 @@ int gpk_init(int device) {
     G.s_leaf = G.s_panel;
   }
   G.cu_reserved = masked;
-  G.ncu = masked ? ncu - 8 : ncu;
+  G.ncu = masked ? ncu - G.ncu_reserved : ncu;
   for (int i = 0; i < 64; ++i) {
     hipEvent_t e;
     GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -207,6 +213,12 @@ int gpk_set_option(const char* key, double value) {
     G.nb_small = (int)value;
   } else if (k == "nb_small_from") {
     G.nb_small_from = (int)value;
+  } else if (k == "outer_until") {
+    G.outer_until = (int)value;
+  } else if (k == "outer_from") {
+    G.outer_from = (int)value;
+  } else if (k == "nb_outer") {
+    G.nb_outer = (int)value;
   } else if (k == "lookahead") {
     G.lookahead = (int)value;
   } else if (k == "gemm_variant") {
@@ -259,6 +271,9 @@ double gpk_get_option(const char* key) {
   if (k == "nb_big_until") return G.nb_big_until;
   if (k == "nb_small") return G.nb_small;
   if (k == "nb_small_from") return G.nb_small_from;
+  if (k == "outer_until") return G.outer_until;
+  if (k == "outer_from") return G.outer_from;
+  if (k == "nb_outer") return G.nb_outer;
   if (k == "xcd_sq") return G.xcd_sq;
   if (k == "leaf_direct_rows") return G.leaf_direct_rows;
   if (k == "pred_small_below") return G.pred_small_below;
@@ -353,7 +368,7 @@ static int model_unpack_L(gpk_model* m, double* L_out_host) {
   // blocks above the panels are never touched by the unpack kernel: the strict upper triangle must be zero
   if (hipMemsetAsync(dOut, 0, (size_t)N * N * 8, s) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
   for (int p = 0; p < m->nP && !rc; ++p)
-    rc = launch_unpack_L(m->Lpanel(p), m->pw[p], m->Npad - m->pc0[p], m->pc0[p], dOut, N, s);
+    rc = launch_unpack_L(m->Lpanel(p), m->pw[p], m->pld[p], m->Npad - m->pc0[p], m->pc0[p], dOut, N, s);
   if (!rc && hipMemcpyAsync(L_out_host, dOut, (size_t)N * N * 8, hipMemcpyDeviceToHost, s) != hipSuccess) rc = gpk_set_err(-2, "D2H failed");
   if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = gpk_set_err(-2, "stream sync failed");
   dev_free(dOut, (size_t)N * N * 8);
@@ -808,6 +823,7 @@ int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, 
     GemmNT g{};
     g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
     g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
+    g.xcd_sq = (G.xcd_sq == 2 && tile == 128) ? 1 : 0;  // option xcd_sq = 2: force the XCD-aware tile order (tests)
     double *dA2 = nullptr, *dB2 = nullptr;
     const int k1 = G.test_gemm_k1;
     if (k1 > 0 && k1 < k) {
@@ -1108,6 +1124,66 @@ int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended) {
   (void)hipEventDestroy(e1);
   dev_free(dA, 128 * 128 * 8); dev_free(dL, 128 * 128 * 8); dev_free(dD, 128 * 128 * 8); dev_free(dinfo, 16);
   dev_free(gA, (size_t)gm * gk * 8); dev_free(gC, (size_t)gm * gm * 8);
+  return 0;
+}
+
+// Feasibility probe for a tile-level critical chain: `reps` steps of [leaf, `nsmall` one-tile-row GEMMs (m = 128, n = 128,
+// k = 128, 64x64 tiles = 4 workgroups each)] on the panel-chain stream, alone and while the update stream runs
+// back-to-back trailing updates.  us per step.
+int gpk_bench_chain_step(int reps, int nsmall, int small_m, double* us_alone, double* us_contended) {
+  GPK_TRY(rt_require());
+  hipStream_t sl = G.s_panel, sm = G.s_main;
+  double *dA = nullptr, *dL = nullptr, *dD = nullptr, *gA = nullptr, *gC = nullptr, *tC = nullptr;
+  int* dinfo = nullptr;
+  const int gm = 8192, gk = 256;
+  GPK_TRY(dev_alloc_t(&dA, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dL, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dD, 128 * 128));
+  GPK_TRY(dev_alloc_t(&dinfo, 4));
+  GPK_TRY(dev_alloc_t(&gA, (size_t)gm * gk));
+  GPK_TRY(dev_alloc_t(&gC, (size_t)gm * gm));
+  GPK_TRY(dev_alloc_t(&tC, (size_t)small_m * 128));
+  std::vector<double> h(128 * 128);
+  for (int i = 0; i < 128; ++i)
+    for (int j = 0; j < 128; ++j) h[i * 128 + j] = (i == j ? 4.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
+  GPK_HIP(hipMemcpy(dA, h.data(), 128 * 128 * 8, hipMemcpyHostToDevice));
+  GPK_HIP(hipMemset(dinfo, 0, 16));
+  GPK_TRY(launch_fill(gA, (size_t)gm * gk, 1e-3, sm));
+  GPK_TRY(launch_fill(gC, (size_t)gm * gm, 1.0, sm));
+  GPK_TRY(launch_fill(tC, (size_t)small_m * 128, 1.0, sm));
+  GPK_HIP(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  auto run_chain = [&](double* out) -> int {
+    GPK_HIP(hipEventRecord(e0, sl));
+    for (int r = 0; r < reps; ++r) {
+      GPK_TRY(launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, 0, sl));
+      for (int q = 0; q < nsmall; ++q) {
+        GemmNT g{};
+        g.A = gA; g.lda = gk; g.B = dD; g.ldb = 128; g.C = tC; g.ldc = 128;
+        g.m = small_m; g.n = 128; g.k = 128; g.sub = (q & 1);
+        GPK_TRY(launch_gemm_nt(g, false, sl));
+      }
+    }
+    GPK_HIP(hipEventRecord(e1, sl));
+    GPK_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *out = 1e3 * ms / reps;
+    return 0;
+  };
+  GPK_TRY(run_chain(us_alone));
+  GemmNT g{};
+  g.A = gA; g.lda = gk; g.B = gA; g.ldb = gk; g.C = gC; g.ldc = gm; g.m = gm; g.n = gm; g.k = gk; g.sub = 1; g.lower = 1;
+  const int nbig = (int)(reps * 0.12) + 20;  // ~0.37 ms each: enough to outlast the chain
+  for (int r = 0; r < nbig; ++r) GPK_TRY(launch_gemm_nt(g, true, sm));
+  GPK_TRY(run_chain(us_contended));
+  GPK_HIP(hipDeviceSynchronize());
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dev_free(dA, 128 * 128 * 8); dev_free(dL, 128 * 128 * 8); dev_free(dD, 128 * 128 * 8); dev_free(dinfo, 16);
+  dev_free(gA, (size_t)gm * gk * 8); dev_free(gC, (size_t)gm * gm * 8); dev_free(tC, (size_t)small_m * 128 * 8);
   return 0;
 }
 

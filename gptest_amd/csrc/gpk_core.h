@@ -22,6 +22,7 @@ struct Runtime {
   hipStream_t s_pred = nullptr;   // y and prediction substitutions pipelined behind the factorisation (fused fit+predict)
   hipStream_t s_leaf = nullptr;   // CU-masked stream owning one reserved CU for the 1-workgroup leaf kernels
   bool cu_reserved = false;
+  int ncu_reserved = 8;
   std::vector<hipEvent_t> ev_ring;
   size_t ev_ring_pos = 0;
   std::map<size_t, std::vector<void*>> pool;
@@ -31,6 +32,11 @@ struct Runtime {
   // single-GPU panel schedule: wide panels (K = nb_big) while the trailing matrix is large and the panel
   // chain hides behind the update, nb in the middle, nb_small at the tail where the chain IS the critical path
   int nb_big = 512, nb_big_until = 8192, nb_small = 128, nb_small_from = 2048, nb_auto = 1;
+  // two-level blocking (single GPU, nb_auto): OUTER panels of nb_outer columns are applied to the trailing matrix as
+  // ONE update with K = nb_outer (the kernel does 56 TFLOP/s at K = 2048 against 44 at K = 256: the C tile traffic
+  // and the accumulator hand-over amortise over 8x the flops); inside an outer block column the panels above are the
+  // inner level.  Active for Npad >= outer_from while more than outer_until columns remain; 0 = one level.
+  int nb_outer = 2048, outer_from = 1 << 30, outer_until = 4096;  // off by default: measured no gain
   int lookahead = 1;
   double last_potrf_enqueue_ms = 0.0, last_pipe_enqueue_ms = 0.0;  // host time spent queueing the last factorisation
   int timing = 0;
@@ -82,8 +88,17 @@ struct gpk_model {
   std::vector<hipEvent_t> ev;
   size_t dws_bytes = 0;       // size dws was allocated with (the nb_big option may change while the handle lives)
   double* shard_loc = nullptr;  // this rank's slice of a sharded prediction: [mean(Mpad) | var(Mpad)] (peers copy from it)
-  std::vector<int> pc0, pw;
+  // inner panels (the unit of the panel chain: leaf factorisations, substitutions): first column, width,
+  // leading dimension of their storage, offset of element (c0, c0) in dL, outer panel they belong to
+  std::vector<int> pc0, pw, pouter;
+  std::vector<long> pld;
   std::vector<size_t> poff;
+  // outer panels (the unit of the trailing update): first column, width, first / one-past-last inner panel; an outer
+  // panel is stored packed, rows oc0.. x ow columns, ld = ow, at dL + ooff.  One level: outer o == inner panel o.
+  int nO = 0;
+  std::vector<int> oc0, ow, ofirst, oend;
+  std::vector<size_t> ooff;
+  double* Lo(int o) const { return dL + ooff[o]; }
   size_t L_elems = 0;
   double *dX = nullptr, *dy = nullptr, *dw = nullptr;
   double *dK = nullptr, *dKcopy = nullptr, *dL = nullptr, *dDinv = nullptr;

@@ -146,21 +146,41 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r) {
   if (P > 1 && keep_k) { delete m; return gpk_set_err(-1, "keep-K models are single-GPU only"); }
   m->Npad = (P > 1) ? round_up(N, nb) : round_up(N, GPK_T);
   m->nT = m->Npad / GPK_T;
-  size_t off = 0;
-  for (int c0 = 0; c0 < m->Npad;) {
+  // panel layout (see gpk_model): inner widths by the remaining size (nb_auto) or uniform nb; outer panels group
+  // the inner ones where the two-level schedule applies
+  auto inner_width = [&](int rem) {
     int w = nb;
     if (P == 1 && G.nb_auto) {
-      const int rem = m->Npad - c0;
       if (rem > G.nb_big_until + G.nb_big) w = G.nb_big;
       else if (rem <= G.nb_small_from) w = G.nb_small;
     }
-    w = std::min(w, m->Npad - c0);
-    m->pc0.push_back(c0);
-    m->pw.push_back(w);
-    m->poff.push_back(off);
-    off += (size_t)(m->Npad - c0) * w;
-    c0 += w;
+    return w;
+  };
+  const bool two_level = (P == 1 && G.nb_auto && G.lookahead && G.nb_outer >= 256 && m->Npad >= G.outer_from);
+  size_t off = 0;
+  for (int c0 = 0; c0 < m->Npad;) {
+    const int rem = m->Npad - c0;
+    int W = std::min(inner_width(rem), rem);
+    if (two_level && rem > G.outer_until) W = std::min(G.nb_outer / 128 * 128, rem);
+    const int o = (int)m->oc0.size();
+    m->oc0.push_back(c0);
+    m->ow.push_back(W);
+    m->ooff.push_back(off);
+    m->ofirst.push_back((int)m->pc0.size());
+    for (int ci = c0; ci < c0 + W;) {
+      const int w = std::min(inner_width(m->Npad - ci), c0 + W - ci);
+      m->pc0.push_back(ci);
+      m->pw.push_back(w);
+      m->pld.push_back(W);
+      m->pouter.push_back(o);
+      m->poff.push_back(off + (size_t)(ci - c0) * W + (ci - c0));
+      ci += w;
+    }
+    m->oend.push_back((int)m->pc0.size());
+    off += (size_t)rem * W;
+    c0 += W;
   }
+  m->nO = (int)m->oc0.size();
   m->nP = (int)m->pc0.size();
   m->L_elems = off;
   m->nloc = 0;
@@ -256,7 +276,7 @@ static int launch_leaf(const double* A, long lda, double* L, long ldl, double* D
 
 int factor_panel(gpk_model* m, int p, hipStream_t s) {
   const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
-  const long ldk = m->ldk;
+  const long ldk = m->ldk, ld = m->pld[p];
   const long kc0 = (m->P > 1) ? (long)(p / m->P) * m->NB : (long)c0;  // local column of global column c0
   double* Lp = m->Lpanel(p);
   const int h = np_ - c0;
@@ -267,20 +287,20 @@ int factor_panel(gpk_model* m, int p, hipStream_t s) {
     if (sb > 0) {
       // A[cs:, cs:cs+128] -= Lp[ro:, 0:ro] * Lp[ro:ro+128, 0:ro]^T
       GemmNT g{};
-      g.A = Lp + (long)ro * w; g.lda = w;
-      g.B = Lp + (long)ro * w; g.ldb = w;
+      g.A = Lp + (long)ro * ld; g.lda = ld;
+      g.B = Lp + (long)ro * ld; g.ldb = ld;
       g.C = Acol; g.ldc = ldk;
       g.m = h - ro; g.n = 128; g.k = ro; g.sub = 1;
       GPK_TRY(launch_gemm_nt(g, false, s));
     }
     double* Dt = m->dDinv + (long)(cs / 128) * 128 * 128;
-    GPK_TRY(launch_leaf(Acol, ldk, Lp + (long)ro * w + sb * 128, w, Dt, m->dinfo, cs, s, h - ro));
+    GPK_TRY(launch_leaf(Acol, ldk, Lp + (long)ro * ld + sb * 128, ld, Dt, m->dinfo, cs, s, h - ro));
     if (h - ro - 128 > 0) {
       // L[cs+128:, sub-panel] = A[cs+128:, cs:cs+128] * Dinv^T
       GemmNT g{};
       g.A = Acol + (long)128 * ldk; g.lda = ldk;
       g.B = Dt; g.ldb = 128;
-      g.C = Lp + (long)(ro + 128) * w + sb * 128; g.ldc = w;
+      g.C = Lp + (long)(ro + 128) * ld + sb * 128; g.ldc = ld;
       g.m = h - ro - 128; g.n = 128; g.k = 128; g.sub = 0;
       GPK_TRY(launch_gemm_nt(g, false, s));
     }
@@ -292,17 +312,36 @@ int factor_panel(gpk_model* m, int p, hipStream_t s) {
 // lower = 1: square region on the diagonal (r0g == c0g, ncols == rows), only tiles on/below it.
 int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hipStream_t s) {
   const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
+  const long ld = m->pld[p];
   const int rows = np_ - r0g;
   if (rows <= 0 || ncols <= 0) return 0;
   double* Lp = m->Lpanel(p);
   GemmNT g{};
-  g.A = Lp + (long)(r0g - c0) * w; g.lda = w;
-  g.B = Lp + (long)(c0g - c0) * w; g.ldb = w;
+  g.A = Lp + (long)(r0g - c0) * ld; g.lda = ld;
+  g.B = Lp + (long)(c0g - c0) * ld; g.ldb = ld;
   g.C = m->dK + (long)r0g * np_ + c0g; g.ldc = np_;
   g.m = rows; g.n = ncols; g.k = w; g.sub = 1; g.lower = lower;
   // Few 128x128 tiles = a latency-bound launch on the panel chain (look-ahead block column, tail of the
   // factorisation): 64x64 tiles put 4x as many CUs on it (84 tiles at K = 256: 70 us -> 64x64: ~20 us).
-  const long tiles = lower ? (long)(rows / 128) * (rows / 128 + 1) / 2 : (long)(rows / 128) * (ncols / 128);
+  const long nc = ncols / 128, nr = rows / 128;
+  const long tiles = lower ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc;
+  if (tiles < G.small_tile_below) return launch_gemm_nt(g, false, s);
+  return launch_gemm_auto(g, s);
+}
+
+// The same for a whole OUTER panel o (K = ow[o], operands in the outer panel's packed storage).
+int outer_update(gpk_model* m, int o, int r0g, int c0g, int ncols, int lower, hipStream_t s) {
+  const int c0 = m->oc0[o], W = m->ow[o], np_ = m->Npad;
+  const int rows = np_ - r0g;
+  if (rows <= 0 || ncols <= 0) return 0;
+  double* Lo = m->Lo(o);
+  GemmNT g{};
+  g.A = Lo + (long)(r0g - c0) * W; g.lda = W;
+  g.B = Lo + (long)(c0g - c0) * W; g.ldb = W;
+  g.C = m->dK + (long)r0g * np_ + c0g; g.ldc = np_;
+  g.m = rows; g.n = ncols; g.k = W; g.sub = 1; g.lower = lower;
+  const long nc = ncols / 128, nr = rows / 128;
+  const long tiles = lower ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc;
   if (tiles < G.small_tile_below) return launch_gemm_nt(g, false, s);
   return launch_gemm_auto(g, s);
 }
@@ -319,8 +358,8 @@ int dist_update(gpk_model* m, int p, int first_block, int nblocks_max, hipStream
   if (rows <= 0 || nb_ <= 0) return 0;
   double* Lp = m->Lpanel(p);
   GemmNT g{};
-  g.A = Lp + (long)w * w; g.lda = w;
-  g.B = g.A; g.ldb = w;
+  g.A = Lp + (long)w * m->pld[p]; g.lda = m->pld[p];
+  g.B = g.A; g.ldb = g.lda;
   g.C = m->dK + (long)r0 * m->ldk + (long)first_block * m->NB; g.ldc = m->ldk;
   g.m = rows; g.n = nb_ * m->NB; g.k = w; g.sub = 1; g.lower = 1;
   g.cyc_P = m->P; g.cyc_r = m->r; g.cyc_NB = m->NB; g.cyc_lg0 = first_block;
@@ -352,16 +391,16 @@ static int pair_update(gpk_model* m, int p, int r0g, hipStream_t s) {
   const int np_ = m->Npad, rows = np_ - r0g;
   if (rows <= 0) return 0;
   const long nt = rows / 128;
-  if (nt * (nt + 1) / 2 < G.small_tile_below || m->pw[p] != m->pw[p + 1]) {  // the kernel wants equal panel widths
+  if (nt * (nt + 1) / 2 < G.small_tile_below || m->pld[p] != m->pld[p + 1]) {  // the kernel wants equal leading dimensions
     GPK_TRY(panel_update(m, p, r0g, r0g, rows, 1, s));
     return panel_update(m, p + 1, r0g, r0g, rows, 1, s);
   }
   const int c0 = m->pc0[p], w = m->pw[p], c1 = m->pc0[p + 1], w1 = m->pw[p + 1];
   GemmNT g{};
-  g.A = m->Lpanel(p) + (long)(r0g - c0) * w; g.lda = w;
-  g.B = g.A; g.ldb = w;
-  g.A2 = m->Lpanel(p + 1) + (long)(r0g - c1) * w1; g.lda2 = w1;
-  g.B2 = g.A2; g.ldb2 = w1;
+  g.A = m->Lpanel(p) + (long)(r0g - c0) * m->pld[p]; g.lda = m->pld[p];
+  g.B = g.A; g.ldb = g.lda;
+  g.A2 = m->Lpanel(p + 1) + (long)(r0g - c1) * m->pld[p + 1]; g.lda2 = m->pld[p + 1];
+  g.B2 = g.A2; g.ldb2 = g.lda2;
   g.k1 = w; g.k = w + w1;
   g.C = m->dK + (long)r0g * np_ + r0g; g.ldc = np_;
   g.m = rows; g.n = rows; g.sub = 1; g.lower = 1;
@@ -465,44 +504,70 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   // (N = 4096: 309 -> 318 posteriors/s, N = 8192: +2 %).  From N = 16384 on they lose: the K-doubled far update does
   // run faster (50 vs 44.5 TFLOP/s) but the three narrow updates per pair it needs (16 % of the flops) cost more
   // than that (N = 16384: 38.1-38.5 vs 36.9-37.05 ms, N = 32768: 241.8 vs 231.9).  1: only up to 8192, 2: always.
-  if (nP >= 6 && (G.pair_update == 2 || (G.pair_update == 1 && m->Npad <= 8192))) return potrf_device_paired(m, after_panel);
+  if (nP >= 6 && m->nO == nP && (G.pair_update == 2 || (G.pair_update == 1 && m->Npad <= 8192)))
+    return potrf_device_paired(m, after_panel);
   GPK_TRY(model_events(m, 3 * nP + 6));
   g_potrf_lookahead_used = 1;
-  hipEvent_t* ev_panel = m->ev.data();        // panel p factored (recorded on s_panel)
-  hipEvent_t* ev_trail = m->ev.data() + nP;   // rest-update of step p done (recorded on s_main)
+  hipEvent_t* ev_panel = m->ev.data();        // inner panel p factored (recorded on s_panel)
+  hipEvent_t* ev_trail = m->ev.data() + nP;   // rest-update of OUTER step o done (recorded on s_main)
   hipEvent_t ev_start = m->ev[2 * nP];
+  const int nO = m->nO, np_ = m->Npad;
+  hipEvent_t* ev_blk = m->ev.data() + 2 * nP + 6;  // outer step o: block column o+1 fully updated (s_main)
+  // Factor the block column of outer panel o on stream s: right-looking over its inner panels, each followed by
+  // its update of the remaining columns OF THIS BLOCK COLUMN (K = inner width).  One level: just factor_panel.
+  // `first_update_after`: what the first of those updates must wait for (the rest of the block column receives the
+  // previous outer panel's update on s_main while the first inner panel is being factored here).
+  auto factor_outer = [&](int o, hipStream_t s, hipEvent_t first_update_after) -> int {
+    const int cend = m->oc0[o] + m->ow[o];
+    for (int p = m->ofirst[o]; p < m->oend[o]; ++p) {
+      GPK_TRY(factor_panel(m, p, s));
+      GPK_HIP(hipEventRecord(ev_panel[p], s));
+      if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, s));
+      if (after_panel) GPK_TRY((*after_panel)(p));
+      const int r0 = m->pc0[p] + m->pw[p];
+      if (cend - r0 > 0) {
+        if (p == m->ofirst[o] && first_update_after) GPK_HIP(hipStreamWaitEvent(s, first_update_after, 0));
+        GPK_TRY(panel_update(m, p, r0, r0, cend - r0, 1, s));
+      }
+    }
+    return 0;
+  };
   // s_panel must not start before the K build queued on s_main has finished
   GPK_HIP(hipEventRecord(ev_start, sm));
   GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
-  GPK_TRY(factor_panel(m, 0, sp));
-  GPK_HIP(hipEventRecord(ev_panel[0], sp));
-  if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + 0, sp));
-  if (after_panel) GPK_TRY((*after_panel)(0));
-  for (int p = 0; p < nP; ++p) {
-    const int r0 = m->pc0[p] + m->pw[p];             // first row/col of the trailing matrix
-    const int wn = (p + 1 < nP) ? m->pw[p + 1] : 0;  // width of the look-ahead block column
-    if (p + 1 < nP) {
-      // (a) s_panel: block column p+1 gets panel p's update, then panel p+1 is factored.
-      if (p > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[p - 1], 0));  // earlier updates of that column
-      GPK_TRY(panel_update(m, p, r0, r0, wn, 0, sp));
-      GPK_TRY(factor_panel(m, p + 1, sp));
-      GPK_HIP(hipEventRecord(ev_panel[p + 1], sp));
-      if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p + 1, sp));
-      if (after_panel) GPK_TRY((*after_panel)(p + 1));
+  GPK_TRY(factor_outer(0, sp, nullptr));
+  for (int o = 0; o < nO; ++o) {
+    const int r0 = m->oc0[o] + m->ow[o];             // first row/col of the trailing matrix
+    const int wn = (o + 1 < nO) ? m->ow[o + 1] : 0;  // width of the next block column
+    const int w1 = (o + 1 < nO) ? m->pw[m->ofirst[o + 1]] : 0;  // ... of its first inner panel: the look-ahead column
+    if (o + 1 < nO) {
+      // (a) s_panel: the look-ahead column gets outer panel o's update (lower trapezoid) ...
+      if (o > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[o - 1], 0));  // earlier updates of that column
+      GPK_TRY(outer_update(m, o, r0, r0, w1, 1, sp));
     }
-    // (b) s_main: the rest of the trailing matrix (lower triangle starting after block column p+1)
-    GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
+    GPK_HIP(hipStreamWaitEvent(sm, ev_panel[m->oend[o] - 1], 0));
+    const long ntr = (np_ - r0 - w1) / 128;
+    const char* tname = (ntr * (ntr + 1) / 2 < G.small_tile_below) ? "trailing_small" : "trailing";
+    if (wn - w1 > 0) {
+      // (b1) s_main: the other columns of block column o+1 first, so that the inner updates of its factorisation
+      // can follow the first inner panel without waiting for the whole trailing update
+      timer_begin(tname, sm, (double)(wn - w1) * (2.0 * (np_ - r0 - w1) - (wn - w1)) * m->ow[o]);
+      GPK_TRY(outer_update(m, o, r0 + w1, r0 + w1, wn - w1, 1, sm));
+      timer_end(tname, sm);
+      GPK_HIP(hipEventRecord(ev_blk[o], sm));
+    }
+    //     ... and block column o+1 is factored on s_panel.
+    if (o + 1 < nO) GPK_TRY(factor_outer(o + 1, sp, (wn - w1 > 0) ? ev_blk[o] : nullptr));
+    // (b2) s_main: the rest of the trailing matrix (lower triangle starting after block column o+1)
     const int r1 = r0 + wn;
-    if (m->Npad - r1 > 0) {
+    if (np_ - r1 > 0) {
       // "trailing" = the launches of the 8-wave kernel (the roofline object of bench.py); the latency-bound
-      // tail that panel_update routes to the 64x64-tile kernel is timed under its own name
-      const long nt = (m->Npad - r1) / 128;
-      const char* tname = (nt * (nt + 1) / 2 < G.small_tile_below) ? "trailing_small" : "trailing";
-      timer_begin(tname, sm, (double)(m->Npad - r1) * (m->Npad - r1) * m->pw[p]);
-      GPK_TRY(panel_update(m, p, r1, r1, m->Npad - r1, 1, sm));
+      // tail that outer_update routes to the 64x64-tile kernel is timed under its own name
+      timer_begin(tname, sm, (double)(np_ - r1) * (np_ - r1) * m->ow[o]);
+      GPK_TRY(outer_update(m, o, r1, r1, np_ - r1, 1, sm));
       timer_end(tname, sm);
     }
-    GPK_HIP(hipEventRecord(ev_trail[p], sm));
+    GPK_HIP(hipEventRecord(ev_trail[o], sm));
   }
   // join: everything after potrf runs on s_main and needs the last panel
   GPK_HIP(hipStreamWaitEvent(sm, ev_panel[nP - 1], 0));
@@ -678,8 +743,8 @@ int trsv_forward(gpk_model* m, double* v) {
   for (int p = 0; p < m->nP; ++p) {
     const int c0 = m->pc0[p], w = m->pw[p], h = m->Npad - c0;
     double* Lp = m->Lpanel(p);
-    GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, v + c0, 0, s));
-    GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, v + c0, v + c0 + w, s));
+    GPK_TRY(launch_diag_solve(Lp, w, m->pld[p], m->dDinv + (long)(c0 / 128) * 128 * 128, v + c0, 0, s));
+    GPK_TRY(launch_gemv_sub(Lp + (long)w * m->pld[p], m->pld[p], h - w, w, v + c0, v + c0 + w, s));
   }
   return 0;
 }
@@ -688,8 +753,8 @@ int trsv_backward(gpk_model* m, double* v) {
   for (int p = m->nP - 1; p >= 0; --p) {
     const int c0 = m->pc0[p], w = m->pw[p], h = m->Npad - c0;
     double* Lp = m->Lpanel(p);
-    GPK_TRY(launch_gemvT_sub(Lp + (long)w * w, w, h - w, w, v + c0 + w, v + c0, m->dws, s));
-    GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, v + c0, 1, s));
+    GPK_TRY(launch_gemvT_sub(Lp + (long)w * m->pld[p], m->pld[p], h - w, w, v + c0 + w, v + c0, m->dws, s));
+    GPK_TRY(launch_diag_solve(Lp, w, m->pld[p], m->dDinv + (long)(c0 / 128) * 128 * 128, v + c0, 1, s));
   }
   return 0;
 }
@@ -715,8 +780,8 @@ int potrf_forward(gpk_model* m, double* v) {
     const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
     double* Lp = m->Lpanel(p);
     GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
-    GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, v + c0, 0, sq));
-    GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, v + c0, v + c0 + w, sq));
+    GPK_TRY(launch_diag_solve(Lp, w, m->pld[p], m->dDinv + (long)(c0 / 128) * 128 * 128, v + c0, 0, sq));
+    GPK_TRY(launch_gemv_sub(Lp + (long)w * m->pld[p], m->pld[p], h - w, w, v + c0, v + c0 + w, sq));
   }
   hipEvent_t ev_out = m->ev[2 * m->nP + 3];
   GPK_HIP(hipEventRecord(ev_out, sq));
@@ -727,6 +792,8 @@ int potrf_forward(gpk_model* m, double* v) {
 // ------------------------------------------------------------------ fused fit (inputs already in HBM)
 static int predict_diag(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s);
 static int predict_update(gpk_model* m, int p, int Mpad, int cg0, int ncols, double* dR, double* dV, hipStream_t s);
+static int predict_outer_update(gpk_model* m, int o, int Mpad, int cg0, int ncols, double* dR, double* dV, hipStream_t s);
+static int predict_step(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s);
 
 // Block-cyclic fit of the rank models living in this process (see potrf_group): every rank builds its block columns
 // of K, the group factors, every rank then holds all of L and runs the y substitution redundantly.
@@ -818,13 +885,12 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     if (m->has_y) {
       double* Lp = m->Lpanel(p);
       GPK_HIP(hipStreamWaitEvent(sy, ev_panel[p], 0));
-      GPK_TRY(launch_diag_solve(Lp, w, m->dDinv + (long)(c0 / 128) * 128 * 128, m->dw + c0, 0, sy));
-      GPK_TRY(launch_gemv_sub(Lp + (long)w * w, w, h - w, w, m->dw + c0, m->dw + c0 + w, sy));
+      GPK_TRY(launch_diag_solve(Lp, w, m->pld[p], m->dDinv + (long)(c0 / 128) * 128 * 128, m->dw + c0, 0, sy));
+      GPK_TRY(launch_gemv_sub(Lp + (long)w * m->pld[p], m->pld[p], h - w, w, m->dw + c0, m->dw + c0 + w, sy));
     }
     if (fuse) {
       if (!m->has_y || sy != sq) GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
-      GPK_TRY(predict_diag(m, p, fp->Mpad, fp->dR, fp->dV, sq));
-      GPK_TRY(predict_update(m, p, fp->Mpad, c0 + w, np_ - c0 - w, fp->dR, fp->dV, sq));
+      GPK_TRY(predict_step(m, p, fp->Mpad, fp->dR, fp->dV, sq));
     }
     if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + 512 + p, sq));
     return 0;
@@ -906,13 +972,14 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
 static int predict_diag(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s) {
   const int np_ = m->Npad;
   const int c0 = m->pc0[p], w = m->pw[p];
+  const long ld = m->pld[p];
   double* Lp = m->Lpanel(p);
   for (int sb = 0; sb < w / 128; ++sb) {
     const int cs = c0 + sb * 128, ro = cs - c0;
     if (sb > 0) {
       GemmNT g{};
       g.A = dV + c0; g.lda = np_;
-      g.B = Lp + (long)ro * w; g.ldb = w;
+      g.B = Lp + (long)ro * ld; g.ldb = ld;
       g.C = dR + cs; g.ldc = np_;
       g.m = Mpad; g.n = 128; g.k = ro; g.sub = 1;
       GPK_TRY(launch_gemm_nt(g, false, s));
@@ -931,52 +998,82 @@ static int predict_update(gpk_model* m, int p, int Mpad, int cg0, int ncols, dou
   if (ncols <= 0) return 0;
   const int np_ = m->Npad;
   const int c0 = m->pc0[p], w = m->pw[p];
+  const long ld = m->pld[p];
   GemmNT g{};
   g.A = dV + c0; g.lda = np_;
-  g.B = m->Lpanel(p) + (long)(cg0 - c0) * w; g.ldb = w;
+  g.B = m->Lpanel(p) + (long)(cg0 - c0) * ld; g.ldb = ld;
   g.C = dR + cg0; g.ldc = np_;
   g.m = Mpad; g.n = ncols; g.k = w; g.sub = 1;
   // few 128x128 tiles (the look-ahead block column): 64x64 tiles put 4x as many CUs on the critical path
   if ((long)(Mpad / 128) * (ncols / 128) < G.pred_small_below) return launch_gemm_nt(g, false, s);
   return launch_gemm_auto(g, s);
 }
+// the same with a whole outer panel: R[:, cg0 : cg0+ncols] -= V[:, outer o] * Lo[(cg0-oc0) : +ncols, :]^T  (K = ow[o])
+static int predict_outer_update(gpk_model* m, int o, int Mpad, int cg0, int ncols, double* dR, double* dV, hipStream_t s) {
+  if (ncols <= 0) return 0;
+  const int np_ = m->Npad;
+  const int c0 = m->oc0[o], W = m->ow[o];
+  GemmNT g{};
+  g.A = dV + c0; g.lda = np_;
+  g.B = m->Lo(o) + (long)(cg0 - c0) * W; g.ldb = W;
+  g.C = dR + cg0; g.ldc = np_;
+  g.m = Mpad; g.n = ncols; g.k = W; g.sub = 1;
+  if ((long)(Mpad / 128) * (ncols / 128) < G.pred_small_below) return launch_gemm_nt(g, false, s);
+  return launch_gemm_auto(g, s);
+}
+// Everything inner panel p contributes to the row substitution, in the two-level order: its diagonal solve, its
+// update of the remaining columns of ITS OUTER block column (K = inner width) and, when p closes the outer panel,
+// the outer panel's update of all columns to the right (K = outer width).
+static int predict_step(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s) {
+  const int o = m->pouter[p];
+  const int cend = m->oc0[o] + m->ow[o], c1 = m->pc0[p] + m->pw[p];
+  GPK_TRY(predict_diag(m, p, Mpad, dR, dV, s));
+  GPK_TRY(predict_update(m, p, Mpad, c1, cend - c1, dR, dV, s));
+  if (p == m->oend[o] - 1) GPK_TRY(predict_outer_update(m, o, Mpad, cend, m->Npad - cend, dR, dV, s));
+  return 0;
+}
 
 // V = R L^-T for Mpad rows (multiple of 128) of width Npad, R destroyed; s_main carries the result.
 int rows_forward_solve(gpk_model* m, int Mpad, double* dR, double* dV) {
   hipStream_t sm = G.s_main, sp = G.s_panel;
-  const int np_ = m->Npad, nP = m->nP;
+  const int np_ = m->Npad, nP = m->nP, nO = m->nO;
   if (!G.lookahead || nP < 3) {
-    for (int p = 0; p < nP; ++p) {
-      GPK_TRY(predict_diag(m, p, Mpad, dR, dV, sm));
-      const int c1 = m->pc0[p] + m->pw[p];
-      GPK_TRY(predict_update(m, p, Mpad, c1, np_ - c1, dR, dV, sm));
-    }
-  } else {
-    // one panel of look-ahead, as in the factorisation: the latency-bound diagonal solves of panel p+1 run on
-    // s_panel while the wide update of panel p runs on s_main.
-    GPK_TRY(model_events(m, 3 * nP + 6));
-    hipEvent_t* ev_diag = m->ev.data();
-    hipEvent_t* ev_upd = m->ev.data() + nP;
-    hipEvent_t ev_start = m->ev[2 * nP];
-    GPK_HIP(hipEventRecord(ev_start, sm));
-    GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
-    GPK_TRY(predict_diag(m, 0, Mpad, dR, dV, sp));
-    GPK_HIP(hipEventRecord(ev_diag[0], sp));
-    for (int p = 0; p < nP; ++p) {
-      const int c1 = m->pc0[p] + m->pw[p];
-      const int wn = (p + 1 < nP) ? m->pw[p + 1] : 0;
-      if (p + 1 < nP) {
-        if (p > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_upd[p - 1], 0));
-        GPK_TRY(predict_update(m, p, Mpad, c1, wn, dR, dV, sp));
-        GPK_TRY(predict_diag(m, p + 1, Mpad, dR, dV, sp));
-        GPK_HIP(hipEventRecord(ev_diag[p + 1], sp));
-      }
-      GPK_HIP(hipStreamWaitEvent(sm, ev_diag[p], 0));
-      GPK_TRY(predict_update(m, p, Mpad, c1 + wn, np_ - c1 - wn, dR, dV, sm));
-      GPK_HIP(hipEventRecord(ev_upd[p], sm));
-    }
-    GPK_HIP(hipStreamWaitEvent(sm, ev_diag[nP - 1], 0));
+    for (int p = 0; p < nP; ++p) GPK_TRY(predict_step(m, p, Mpad, dR, dV, sm));
+    return 0;
   }
+  // one outer panel of look-ahead, as in the factorisation: the latency-bound diagonal solves (and inner updates)
+  // of outer block column o+1 run on s_panel while the wide update of outer panel o runs on s_main.
+  auto outer_diag = [&](int o, hipStream_t s) -> int {
+    const int cend = m->oc0[o] + m->ow[o];
+    for (int p = m->ofirst[o]; p < m->oend[o]; ++p) {
+      const int c1 = m->pc0[p] + m->pw[p];
+      GPK_TRY(predict_diag(m, p, Mpad, dR, dV, s));
+      GPK_TRY(predict_update(m, p, Mpad, c1, cend - c1, dR, dV, s));
+    }
+    return 0;
+  };
+  GPK_TRY(model_events(m, 3 * nP + 6));
+  hipEvent_t* ev_diag = m->ev.data();
+  hipEvent_t* ev_upd = m->ev.data() + nP;
+  hipEvent_t ev_start = m->ev[2 * nP];
+  GPK_HIP(hipEventRecord(ev_start, sm));
+  GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
+  GPK_TRY(outer_diag(0, sp));
+  GPK_HIP(hipEventRecord(ev_diag[0], sp));
+  for (int o = 0; o < nO; ++o) {
+    const int c1 = m->oc0[o] + m->ow[o];
+    const int wn = (o + 1 < nO) ? m->ow[o + 1] : 0;
+    if (o + 1 < nO) {
+      if (o > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_upd[o - 1], 0));
+      GPK_TRY(predict_outer_update(m, o, Mpad, c1, wn, dR, dV, sp));
+      GPK_TRY(outer_diag(o + 1, sp));
+      GPK_HIP(hipEventRecord(ev_diag[o + 1], sp));
+    }
+    GPK_HIP(hipStreamWaitEvent(sm, ev_diag[o], 0));
+    GPK_TRY(predict_outer_update(m, o, Mpad, c1 + wn, np_ - c1 - wn, dR, dV, sm));
+    GPK_HIP(hipEventRecord(ev_upd[o], sm));
+  }
+  GPK_HIP(hipStreamWaitEvent(sm, ev_diag[nO - 1], 0));
   return 0;
 }
 
@@ -990,7 +1087,7 @@ int rows_backward_prepare(gpk_model* m, double* dU, double* dDinvT, hipStream_t 
   const int np_ = m->Npad;
   for (int p = 0; p < m->nP; ++p) {
     const int c0 = m->pc0[p], w = m->pw[p];
-    GPK_TRY(launch_transpose(m->Lpanel(p), w, np_ - c0, w, dU + (long)c0 * np_ + c0, np_, s));
+    GPK_TRY(launch_transpose(m->Lpanel(p), m->pld[p], np_ - c0, w, dU + (long)c0 * np_ + c0, np_, s));
   }
   return launch_transpose(m->dDinv, 128, m->nT * 128, 128, dDinvT, (long)m->nT * 128, s);
 }
@@ -1055,7 +1152,7 @@ int nlml_grad_device(gpk_model* m, double* h_grad) {
   if (m->P > 1) return gpk_set_err(-1, "gpk_nlml_grad: not available on a block-cyclic (multi-GPU) model");
   if (!m->has_y) return gpk_set_err(-1, "gpk_nlml_grad: model was fitted without targets");
   hipStream_t s = G.s_main;
-  const int np_ = m->Npad, nP = m->nP, N = m->N, d = m->d;
+  const int np_ = m->Npad, N = m->N, d = m->d;
   const size_t sq = (size_t)np_ * np_;
   const int nt = (N + 127) / 128;
   double *dR = nullptr, *dV = nullptr, *dNK = nullptr, *dalpha = nullptr, *dpart = nullptr, *dout = nullptr;
@@ -1081,18 +1178,23 @@ int nlml_grad_device(gpk_model* m, double* h_grad) {
     GPK_HIP(hipMemsetAsync(dV, 0, sq * 8, s));
     GPK_HIP(hipMemsetAsync(dNK, 0, sq * 8, s));
     GPK_TRY(launch_set_diag(dR, np_, np_, 1.0, s));
-    for (int p = 0; p < nP; ++p) {
-      const int c1 = m->pc0[p] + m->pw[p];
-      GPK_TRY(predict_diag(m, p, c1, dR, dV, s));
-      GPK_TRY(predict_update(m, p, c1, c1, np_ - c1, dR, dV, s));
+    // both sweeps by OUTER panels (K = outer width for the wide updates); rows restricted to the non-zero part
+    for (int o = 0; o < m->nO; ++o) {
+      const int cend = m->oc0[o] + m->ow[o];
+      for (int p = m->ofirst[o]; p < m->oend[o]; ++p) {
+        const int c1 = m->pc0[p] + m->pw[p];
+        GPK_TRY(predict_diag(m, p, c1, dR, dV, s));
+        GPK_TRY(predict_update(m, p, c1, c1, cend - c1, dR, dV, s));
+      }
+      GPK_TRY(predict_outer_update(m, o, cend, cend, np_ - cend, dR, dV, s));
     }
-    for (int p = 0; p < nP; ++p) {
-      const int c0 = m->pc0[p], w = m->pw[p];
+    for (int o = 0; o < m->nO; ++o) {
+      const int c0 = m->oc0[o], W = m->ow[o];
       GemmNT g{};
       g.A = dV + c0; g.lda = np_;
       g.B = dV + c0; g.ldb = np_;
       g.C = dNK; g.ldc = np_;
-      g.m = c0 + w; g.n = c0 + w; g.k = w; g.sub = 1; g.lower = 1;
+      g.m = c0 + W; g.n = c0 + W; g.k = W; g.sub = 1; g.lower = 1;
       GPK_TRY(launch_gemm_auto(g, s));
     }
     timer_end("grad_inv", s);

@@ -83,13 +83,13 @@ int launch_gemv(const double* A, long lda, int m, int k, const double* x, double
 int launch_gemv_sub(const double* A, long lda, int m, int k, const double* x, double* y, hipStream_t s);
 // y[0:k) -= A[m x k]^T x[0:m)  -- column sums, deterministic two-stage (ws >= 64*k doubles)
 int launch_gemvT_sub(const double* A, long lda, int m, int k, const double* x, double* y, double* ws, hipStream_t s);
-// diag-block solves for one panel of width w (multiple of 128) at L (ld w): forward x = Lpp^-1 b ; backward x = Lpp^-T b
-int launch_diag_solve(const double* Lp, int w, const double* Dinv, double* b, int transpose, hipStream_t s);
+// diag-block solves for one panel of width w (multiple of 128) at L (leading dimension ld): forward x = Lpp^-1 b ; backward x = Lpp^-T b
+int launch_diag_solve(const double* Lp, int w, long ld, const double* Dinv, double* b, int transpose, hipStream_t s);
 int launch_transpose(const double* in, long ldin, int rows, int cols, double* out, long ldout, hipStream_t s);
 int launch_fill(double* p, size_t n, double v, hipStream_t s);
 int launch_stamp(unsigned long long* out, hipStream_t s);
 int launch_set_diag(double* p, long ld, int n, double v, hipStream_t s);
-int launch_unpack_L(const double* Lp, int w, int h, int c0, double* out, long ldout, hipStream_t s);
+int launch_unpack_L(const double* Lp, int w, long ld, int h, int c0, double* out, long ldout, hipStream_t s);
 int launch_gather2d(const double* K, long ldk, const long long* idx, int nidx, double* out, hipStream_t s);
 
 // ---------------------------------------------------------------- preference-GP Laplace kernels (k_pref.hip)

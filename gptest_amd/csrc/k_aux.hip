@@ -171,7 +171,7 @@ __device__ inline void tile_col_dot(const d2v (&v)[8], double xr, int part, int 
   }
 }
 
-__global__ __launch_bounds__(1024) void diag_solve_kernel(const double* __restrict__ Lp, int w,
+__global__ __launch_bounds__(1024) void diag_solve_kernel(const double* __restrict__ Lp, int w, long ld,
                                                           const double* __restrict__ Dinv, double* __restrict__ b,
                                                           int transpose) {
   extern __shared__ double sh[];  // x[w] | t[128] | wp[16][128]
@@ -195,11 +195,11 @@ __global__ __launch_bounds__(1024) void diag_solve_kernel(const double* __restri
         const bool have_next = !(last_of_row && s == ns - 1);
         if (have_next) {
           if (last_of_row) {  // next: L(s+1,0)
-            tile_load(Lp + (long)(s + 1) * 128 * w, w, r, part, nxt);
+            tile_load(Lp + (long)(s + 1) * 128 * ld, ld, r, part, nxt);
           } else if (tt + 1 == s) {  // next: D(s)
             tile_load(Dinv + (long)s * 128 * 128, 128, r, part, nxt);
           } else {  // next: L(s, tt+1)
-            tile_load(Lp + (long)s * 128 * w + (tt + 1) * 128, w, r, part, nxt);
+            tile_load(Lp + (long)s * 128 * ld + (tt + 1) * 128, ld, r, part, nxt);
           }
         }
         if (!last_of_row) {
@@ -229,12 +229,12 @@ __global__ __launch_bounds__(1024) void diag_solve_kernel(const double* __restri
         const bool have_next = !(is_diag && s == 0);
         if (have_next) {
           if (is_diag) {  // next: L(ns-1, s-1) or D(s-1) when s-1 == ns-1 (impossible) -> first tile of row s-1 chain
-            if (ns - 1 > s - 1) tile_load(Lp + (long)(ns - 1) * 128 * w + (s - 1) * 128, w, r, part, nxt);
+            if (ns - 1 > s - 1) tile_load(Lp + (long)(ns - 1) * 128 * ld + (s - 1) * 128, ld, r, part, nxt);
             else tile_load(Dinv + (long)(s - 1) * 128 * 128, 128, r, part, nxt);
           } else if (u - 1 == s) {  // next: D(s)
             tile_load(Dinv + (long)s * 128 * 128, 128, r, part, nxt);
           } else {  // next: L(u-1, s)
-            tile_load(Lp + (long)(u - 1) * 128 * w + s * 128, w, r, part, nxt);
+            tile_load(Lp + (long)(u - 1) * 128 * ld + s * 128, ld, r, part, nxt);
           }
         }
         if (!is_diag) {
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(1024) void diag_solve_kernel(const double* __restri
   __syncthreads();
   for (int i = tid; i < w; i += 1024) b[i] = x[i];
 }
-int launch_diag_solve(const double* Lp, int w, const double* Dinv, double* b, int transpose, hipStream_t s) {
-  hipLaunchKernelGGL(diag_solve_kernel, dim3(1), dim3(1024), (size_t)(w + 128 + 16 * 128) * sizeof(double), s, Lp, w, Dinv,
-                     b, transpose);
+int launch_diag_solve(const double* Lp, int w, long ld, const double* Dinv, double* b, int transpose, hipStream_t s) {
+  hipLaunchKernelGGL(diag_solve_kernel, dim3(1), dim3(1024), (size_t)(w + 128 + 16 * 128) * sizeof(double), s, Lp, w, ld,
+                     Dinv, b, transpose);
   GPK_HIP(hipGetLastError());
   return 0;
 }
@@ -314,20 +314,20 @@ int launch_fill(double* p, size_t n, double v, hipStream_t s) {
 }
 
 // panel (h x w, ld w, first global row/col = c0) -> dense lower-triangular out (ld ldout)
-__global__ void unpack_L_kernel(const double* __restrict__ Lp, int w, int h, int c0, double* __restrict__ out, long ldout,
-                                int nmax) {
+__global__ void unpack_L_kernel(const double* __restrict__ Lp, int w, long ld, int h, int c0, double* __restrict__ out,
+                                long ldout, int nmax) {
   const int r = blockIdx.x;  // row inside the panel
   const int gr = c0 + r;
   if (gr >= nmax) return;
   for (int c = threadIdx.x; c < w; c += blockDim.x) {
     const int gc = c0 + c;
     if (gc >= nmax) continue;
-    out[(long)gr * ldout + gc] = (gc <= gr) ? Lp[(long)r * w + c] : 0.0;
+    out[(long)gr * ldout + gc] = (gc <= gr) ? Lp[(long)r * ld + c] : 0.0;
   }
 }
-int launch_unpack_L(const double* Lp, int w, int h, int c0, double* out, long ldout, hipStream_t s) {
+int launch_unpack_L(const double* Lp, int w, long ld, int h, int c0, double* out, long ldout, hipStream_t s) {
   // rows beyond ldout (= N) are padding and are skipped inside the kernel via nmax = ldout
-  hipLaunchKernelGGL(unpack_L_kernel, dim3(h), dim3(256), 0, s, Lp, w, h, c0, out, ldout, (int)ldout);
+  hipLaunchKernelGGL(unpack_L_kernel, dim3(h), dim3(256), 0, s, Lp, w, ld, h, c0, out, ldout, (int)ldout);
   GPK_HIP(hipGetLastError());
   return 0;
 }

@@ -43,12 +43,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
   int ti, tj;
   const int ntn = g.n / BT;
   if (g.lower && g.cyc_P == 0) {
+    // lower trapezoid (m >= n, C(0,0) on the diagonal): the n x n triangle first, then the full rows below it
     int id = blockIdx.x;
-    int t = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
-    while (t * (t + 1) / 2 > id) --t;
-    while ((t + 1) * (t + 2) / 2 <= id) ++t;
-    ti = t;
-    tj = id - t * (t + 1) / 2;
+    const int tri = ntn * (ntn + 1) / 2;
+    if (id < tri) {
+      int t = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+      while (t * (t + 1) / 2 > id) --t;
+      while ((t + 1) * (t + 2) / 2 <= id) ++t;
+      ti = t;
+      tj = id - t * (t + 1) / 2;
+    } else {
+      id -= tri;
+      ti = ntn + id / ntn;
+      tj = id % ntn;
+    }
   } else {
     ti = blockIdx.x / ntn;
     tj = blockIdx.x % ntn;
@@ -171,12 +179,18 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     const int sq = (seq >> 6) * 8 + xcd, slot = seq & 63;
     const int SN = (ntn + 7) >> 3;
     int I, J;
-    if (g.lower) {
-      int r = (int)((sqrtf(8.0f * (float)sq + 1.0f) - 1.0f) * 0.5f);
-      while (r * (r + 1) / 2 > sq) --r;
-      while ((r + 1) * (r + 2) / 2 <= sq) ++r;
-      I = r;
-      J = sq - r * (r + 1) / 2;
+    if (g.lower) {  // lower trapezoid of squares: SN x SN triangle, then full rows of SN squares
+      const int tri = SN * (SN + 1) / 2;
+      if (sq < tri) {
+        int r = (int)((sqrtf(8.0f * (float)sq + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > sq) --r;
+        while ((r + 1) * (r + 2) / 2 <= sq) ++r;
+        I = r;
+        J = sq - r * (r + 1) / 2;
+      } else {
+        I = SN + (sq - tri) / SN;
+        J = (sq - tri) % SN;
+      }
     } else {
       I = sq / SN;
       J = sq - I * SN;
@@ -186,11 +200,18 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     if (ti >= ntm || tj >= ntn || (g.lower && tj > ti)) return;
   } else if (g.lower && g.cyc_P == 0) {
     int id = blockIdx.x;
-    int t = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
-    while (t * (t + 1) / 2 > id) --t;
-    while ((t + 1) * (t + 2) / 2 <= id) ++t;
-    ti = t;
-    tj = id - t * (t + 1) / 2;
+    const int tri = ntn * (ntn + 1) / 2;
+    if (id < tri) {
+      int t = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+      while (t * (t + 1) / 2 > id) --t;
+      while ((t + 1) * (t + 2) / 2 <= id) ++t;
+      ti = t;
+      tj = id - t * (t + 1) / 2;
+    } else {
+      id -= tri;
+      ti = ntn + id / ntn;
+      tj = id % ntn;
+    }
   } else {
     ti = blockIdx.x / ntn;
     tj = blockIdx.x % ntn;
@@ -315,15 +336,15 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
   const int ntm = g.m / BT, ntn = g.n / BT;
   long nblk;
   if (g.lower && g.cyc_P == 0) {
-    if (g.m != g.n) return gpk_set_err(-1, "gemm_nt: lower needs a square C (m=%d n=%d)", g.m, g.n);
-    nblk = (long)ntm * (ntm + 1) / 2;
+    if (g.m < g.n) return gpk_set_err(-1, "gemm_nt: lower needs m >= n (m=%d n=%d)", g.m, g.n);
+    nblk = (long)ntn * (ntn + 1) / 2 + (long)(ntm - ntn) * ntn;
   } else {
     nblk = (long)ntm * ntn;
   }
   if (tile128 && g_gemm_variant == 8) {
     if (g.xcd_sq && g.cyc_P == 0) {  // whole 8x8 squares, 8 squares (one per XCD) per round
       const long SM = (ntm + 7) / 8, SN = (ntn + 7) / 8;
-      const long nsq = g.lower ? SM * (SM + 1) / 2 : SM * SN;
+      const long nsq = g.lower ? SN * (SN + 1) / 2 + (SM - SN) * SN : SM * SN;
       nblk = ((nsq + 7) / 8) * 8 * 64;
     }
     if (g.k1 > 0) hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, g);

@@ -48,6 +48,28 @@ def test_mfma_gemm_nt(gpk, m, n, k, tile, sub, lower):
         np.testing.assert_allclose(C, ref, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("m,n,k,tile", [(512, 256, 64, 128), (640, 128, 32, 64), (2304, 1152, 48, 128), (384, 384, 16, 64)])
+def test_mfma_gemm_nt_lower_trapezoid(gpk, m, n, k, tile):
+    """lower with m >= n: the n x n triangle of tiles plus the full rows below (the shape of an update restricted to
+    a block column: look-ahead column, inner updates of the two-level schedule)."""
+    rng = np.random.RandomState(m + n)
+    A = rng.randn(m, k)
+    C0 = rng.randn(m, n)
+    C = C0.copy()
+    B = np.ascontiguousarray(A[:n])
+    for variant, xcd in ([(8, 1), (8, 2), (4, 1)] if tile == 128 else [(8, 1)]):
+        gpk.set_option("gemm_variant", variant)
+        gpk.set_option("xcd_sq", xcd)   # 2: force the XCD-aware 8x8-square tile order of the big updates
+        C[:] = C0
+        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, 1, tile) == 0, gpk.last_error()
+        ref = C0 - A @ B.T
+        mask = np.zeros((m, n), bool)
+        for ti in range(m // tile):
+            mask[ti * tile:(ti + 1) * tile, :min(n, (ti + 1) * tile)] = True
+        np.testing.assert_allclose(C[mask], ref[mask], rtol=1e-12, atol=1e-12)
+        np.testing.assert_array_equal(C[~mask], C0[~mask])
+
+
 @pytest.mark.parametrize("sub", [0, 1])
 def test_tile_sizes_round_identically(gpk, sub):
     """The schedule picks 64x64 or 128x128 tiles by launch size; the factor must not depend on that choice
@@ -831,24 +853,37 @@ def test_gppref_predict_latent_reproduces_mode_at_training_points(gpk):
     {"nb": 128},                                         # uniform panels instead of the 512/256/128 schedule
     {"pair_update": 0},                                  # one panel per trailing update
     {"pair_update": 2, "nb": 128},                       # paired updates on more than five panels
+    # two-level blocking (outer panels applied with K = nb_outer) forced onto a small problem, several shapes
+    {"nb_outer": 512, "outer_from": 256, "outer_until": 256, "nb_big": 256, "nb_big_until": 512, "nb_small_from": 256},
+    {"nb_outer": 768, "outer_from": 256, "outer_until": 128, "nb_big": 256, "nb_big_until": 0, "nb_small_from": 0},
+    {"nb_outer": 512, "outer_from": 256, "outer_until": 600, "pipe_interleave": 1},
+    {"nb_outer": 1024, "outer_from": 256, "outer_until": 0, "fuse_predict": 0},
+    {"nb_outer": 0},
 ])
 def test_option_paths_keep_parity(gpk, opts):
     """Every switch that selects another kernel or schedule must leave the posterior within the parity bar."""
     from gptest_amd import GPr
     from oracle import gpr_oracle as orc
-    defaults = {"nb": 256, "leaf_algo": 1, "small_tile_below": 256, "pred_small_below": 300, "pipe_interleave": 0,
-                "fuse_predict": 1, "lookahead": 1, "pair_update": 1, "nb_auto": 1}   # "nb" switches nb_auto off: nb_auto is restored last
     x, y, z, lh = orc.synthetic_problem(1500, 3, M=130, seed=21)
     nl, fz, cov = orc.posterior_efficient(lh, x, y, z)
-    try:
-        for k, v in opts.items():
-            gpk.set_option(k, v)
-        gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", x, y)
-        mean, var = gp.compute_prediction(z)
-        nlml = gp.compute_likelihood(lh).flat[0]
-    finally:
-        for k, v in defaults.items():
-            gpk.set_option(k, v)
+    for k, v in opts.items():       # restored by the autouse option fixture
+        gpk.set_option(k, v)
+    gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", x, y)
+    mean, var = gp.compute_prediction(z)
+    nlml = gp.compute_likelihood(lh).flat[0]
+    # and the cached-factor consumers on the same (possibly two-level) layout: gradient, many-RHS solve, L itself
+    _, grad = gp.compute_likelihood_gradient(lh)
+    gref = orc.nlml_gradient(lh, x, y)
+    np.testing.assert_allclose(grad, gref, rtol=RTOL, atol=RTOL * np.abs(gref).max())
+    h, _ = gp._fitted(lh)
+    B = np.ascontiguousarray(np.random.RandomState(1).randn(1500, 20))
+    out = np.empty_like(B)
+    assert gpk.lib().gpk_solve(h.ptr, _ptr(B), 20, _ptr(out)) == 0, gpk.last_error()
+    K = orc.kxx(lh, x)
+    np.testing.assert_allclose(K @ out, B, rtol=0, atol=1e-8)
+    Lg = np.empty((1500, 1500))
+    assert gpk.lib().gpk_model_get_L(h.ptr, _ptr(Lg)) == 0
+    np.testing.assert_allclose(Lg @ Lg.T, K, rtol=0, atol=1e-11)
     assert abs(nlml - nl) <= RTOL * abs(nl)
     np.testing.assert_allclose(mean, fz, rtol=RTOL, atol=RTOL * np.abs(fz).max())
     np.testing.assert_allclose(var, cov, rtol=RTOL, atol=RTOL * np.abs(cov).max())
