@@ -125,8 +125,9 @@ class _Handle(object):
         self.ptr = None
 
 
-def fit_handle(X, y, log_hyp, jitter=0.0, keep_k=False):
-    """gpk_fit -> (_Handle, nlml).  Raises numpy.linalg.LinAlgError if K is not positive definite."""
+def fit_handle(X, y, log_hyp, jitter=0.0, keep_k=False, k_only=False):
+    """gpk_fit -> (_Handle, nlml).  Raises numpy.linalg.LinAlgError if K is not positive definite.
+    ``k_only`` (with ``keep_k`` and ``y=None``): K is built and kept in HBM, nothing is factored."""
     _lib.init()
     X = _as_points(X)
     lh = np.ascontiguousarray(log_hyp, dtype=np.float64)
@@ -141,7 +142,7 @@ def fit_handle(X, y, log_hyp, jitter=0.0, keep_k=False):
     h = ctypes.c_void_p()
     nlml = ctypes.c_double()
     rc = _lib.lib().gpk_fit(X.ctypes.data_as(_lib.c_double_p), yp, X.shape[0], X.shape[1],
-                            lh.ctypes.data_as(_lib.c_double_p), float(jitter), 1 if keep_k else 0,
+                            lh.ctypes.data_as(_lib.c_double_p), float(jitter), (1 if keep_k else 0) | (2 if k_only else 0),
                             ctypes.byref(h), ctypes.byref(nlml))
     _lib.check(rc, "gpk_fit")
     return _Handle(h), nlml.value

@@ -59,6 +59,8 @@ def _bind(l):
         "gpk_free": (i, [vp]),
         "gpk_pref_laplace": (i, [vp, ctypes.POINTER(ctypes.c_longlong), dp, i, d, dp, d, i, dp, ctypes.POINTER(ctypes.c_int), dp]),
         "gpk_pref_predict": (i, [vp, ctypes.POINTER(ctypes.c_longlong), dp, i, d, dp, dp, i, dp, dp]),
+        "gpk_class_laplace": (i, [vp, dp, i, dp, d, i, dp, ctypes.POINTER(ctypes.c_int), dp]),
+        "gpk_class_predict": (i, [vp, dp, i, dp, dp, i, dp, dp, dp]),
         "gpk_test_rccl_selfcheck": (i, [i]),
         "gpk_last_timing": (i, [cp, dp, dp]),
         "gpk_last_timing_work": (i, [cp, dp]),

@@ -401,8 +401,11 @@ int gpk_fit(const double* X, const double* y, int N, int d, const double* log_hy
             gpk_model** handle_out, double* nlml_out) {
   if (!X || !log_hyp || !handle_out) return gpk_set_err(-1, "gpk_fit: null pointer");
   *handle_out = nullptr;
+  if ((flags & 2) && !(flags & 1)) return gpk_set_err(-1, "gpk_fit: flag 2 (K only, no factorisation) needs flag 1 (keep K)");
+  if ((flags & 2) && y) return gpk_set_err(-1, "gpk_fit: flag 2 (K only) takes no targets");
   gpk_model* m = nullptr;
   GPK_TRY(model_create(&m, N, d, (flags & 1) != 0));
+  m->k_only = (flags & 2) != 0;
   hipStream_t s = G.s_main;
   int rc = decode_hyp(log_hyp, d, jitter, m);
   if (!rc && hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
@@ -476,7 +479,7 @@ int gpk_fit_predict(const double* X, const double* y, int N, int d, const double
 int gpk_predict(gpk_model* m, const double* Z, int M, double* mean_out, double* var_out) {
   GPK_TRY(rt_require());
   if (!m || !Z || !mean_out || !var_out) return gpk_set_err(-1, "gpk_predict: null pointer");
-  if (!m->has_y) return gpk_set_err(-1, "gpk_predict: model was fitted without targets");
+  if (!m->has_y || !m->factored) return gpk_set_err(-1, "gpk_predict: model was fitted without targets");
   if (M < 1) return gpk_set_err(-1, "gpk_predict: M=%d must be >= 1", M);
   hipStream_t s = G.s_main;
   double* dZ = nullptr;
@@ -497,6 +500,7 @@ static int solve_common(gpk_model* m, const double* B, int nrhs, double* X_out, 
   if (!m || !B || !X_out) return gpk_set_err(-1, "gpk_solve: null pointer");
   if (nrhs < 1) return gpk_set_err(-1, "gpk_solve: nrhs=%d must be >= 1", nrhs);
   if (m->P != 1) return gpk_set_err(-1, "gpk_solve: single-GPU models only");
+  if (!m->factored) return gpk_set_err(-1, "gpk_solve: the model holds no factorisation");
   hipStream_t s = G.s_main;
   const int N = m->N, np_ = m->Npad;
   const int Mpad = round_up(nrhs, 128);
@@ -624,6 +628,7 @@ int gpk_model_scalar(gpk_model* m, int which, double* out) {
 int gpk_model_get_L(gpk_model* m, double* L_out) {
   GPK_TRY(rt_require());
   if (!m || !L_out) return gpk_set_err(-1, "gpk_model_get_L: null pointer");
+  if (!m->factored) return gpk_set_err(-1, "gpk_model_get_L: the model holds no factorisation");
   return model_unpack_L(m, L_out);
 }
 

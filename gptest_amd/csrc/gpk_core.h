@@ -68,6 +68,22 @@ int dev_alloc(void** p, size_t bytes);
 void dev_free(void* p, size_t bytes);
 template <class T> int dev_alloc_t(T** p, size_t n) { return dev_alloc((void**)p, n * sizeof(T)); }
 
+// Scratch device buffers of one API call: returned to the pool when the call ends, whichever way it ends (the update
+// stream is drained first, so nothing queued can still touch them).
+struct Scratch {
+  std::vector<std::pair<void*, size_t>> bufs;
+  template <class T> int get(T** p, size_t n) {
+    *p = nullptr;
+    GPK_TRY(dev_alloc_t(p, n));
+    bufs.emplace_back((void*)*p, n * sizeof(T));
+    return 0;
+  }
+  ~Scratch() {
+    if (!bufs.empty() && G.inited) (void)hipStreamSynchronize(G.s_main);
+    for (auto& b : bufs) dev_free(b.first, b.second);
+  }
+};
+
 void timer_begin(const char* stage, hipStream_t s, double work = 0.0);
 void timer_end(const char* stage, hipStream_t s);
 void timers_reset();
@@ -110,6 +126,8 @@ struct gpk_model {
   double nlml = 0, logdet = 0, quad = 0;
   int info = 0;
   bool has_y = false, keep_k = false;
+  bool k_only = false;   // gpk_fit flag 2: K built and kept, nothing factored (classification factors B = I + W^1/2 K W^1/2 instead)
+  bool factored = false;
   double* Lpanel(int p) const { return dL + poff[p]; }
 };
 

@@ -838,6 +838,7 @@ int fit_group(gpk_model* const* ms, int n) {
     gpk_model* m = ms[i];
     m->info = worst;
     if (worst > 0) continue;
+    m->factored = true;
     m->logdet = hs[2 * i];
     m->quad = m->has_y ? hs[2 * i + 1] : 0.0;
     m->nlml = m->has_y ? 0.5 * m->quad + m->logdet + 0.5 * m->N * std::log(2.0 * M_PI) : m->logdet;  // GPr.py:64-69
@@ -860,6 +861,11 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   timer_end("kbuild", s);
   if (m->keep_k)
     GPK_HIP(hipMemcpyAsync(m->dKcopy, m->dK, (size_t)np_ * np_ * 8, hipMemcpyDeviceToDevice, s));
+  if (m->k_only) {
+    if (!m->keep_k) return gpk_set_err(-1, "internal: a K-only model must keep K");
+    GPK_HIP(hipStreamSynchronize(s));
+    return 0;
+  }
   timer_begin("potrf", s);
   hipEvent_t ev_kb = nullptr;
   const bool fuse = fp && G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3;
@@ -958,6 +964,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   GPK_HIP(hipStreamSynchronize(s));
   m->info = hinfo;
   if (hinfo > 0) return hinfo > m->N ? m->N : hinfo;
+  m->factored = true;
   m->logdet = hs[0];
   m->quad = m->has_y ? hs[1] : 0.0;
   // GPr.py:64-69: err_y + det_Kxx + occams_razor

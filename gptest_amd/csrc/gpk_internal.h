@@ -106,6 +106,14 @@ int launch_maxabsdiff(const double* a, const double* b, int n, double* out, hipS
 int launch_sum(const double* a, int n, double* out, hipStream_t s);
 int launch_sub(const double* a, const double* b, int n, double* out, hipStream_t s);
 
+// ---------------------------------------------------------------- classification Laplace kernels (k_class.hip)
+int launch_class_stats(const double* y, const double* f, int n, int link, double* g, double* w, double* sw, double* logp,
+                       hipStream_t s);
+int launch_class_ew(const double* p, const double* q, const double* r, int n, int mode, double* out, hipStream_t s);
+int launch_class_scale_rows(const double* R, long ldr, const double* sw, int n, int rows, int rows_pad, int npad, double* U,
+                            long ldu, hipStream_t s);
+int launch_class_prob(const double* mean, const double* var, int n, int link, double* prob, hipStream_t s);
+
 // nlml gradient terms over A = Kinv - alpha alpha^T, NK = -Kinv (lower triangle valid); partial >= nt*nt*(d+2)
 int launch_nlml_grad_terms(const double* X, int N, int d, const double* NK, long ldk, const double* alpha, const SEParams& p,
                            double* partial, double* out, hipStream_t s);

@@ -10,7 +10,7 @@ extern "C" int gpk_pref_laplace(gpk_model* m, const long long* uvi, const double
                                 double* ferr_trace) {
   GPK_TRY(rt_require());
   if (!m || !uvi || !y || !f_inout) return gpk_set_err(-1, "gpk_pref_laplace: null pointer");
-  if (!m->dKcopy) return gpk_set_err(-1, "gpk_pref_laplace: fit the model with the keep-K flag");
+  if (!m->dKcopy || !m->factored) return gpk_set_err(-1, "gpk_pref_laplace: fit the model with the keep-K flag (and a factorisation)");
   if (m->P != 1) return gpk_set_err(-1, "gpk_pref_laplace: single-GPU models only");
   if (npairs < 1 || max_iter < 1 || !(sigma > 0.0)) return gpk_set_err(-1, "gpk_pref_laplace: bad arguments");
   const int nx = m->N, np_ = m->Npad;
@@ -123,7 +123,7 @@ extern "C" int gpk_pref_predict(gpk_model* m, const long long* uvi, const double
                                 const double* f_hat, const double* Z, int M, double* mean_out, double* var_out) {
   GPK_TRY(rt_require());
   if (!m || !uvi || !y || !f_hat || !Z || !mean_out || !var_out) return gpk_set_err(-1, "gpk_pref_predict: null pointer");
-  if (!m->dKcopy) return gpk_set_err(-1, "gpk_pref_predict: fit the model with the keep-K flag");
+  if (!m->dKcopy || !m->factored) return gpk_set_err(-1, "gpk_pref_predict: fit the model with the keep-K flag (and a factorisation)");
   if (m->P != 1) return gpk_set_err(-1, "gpk_pref_predict: single-GPU models only");
   if (npairs < 1 || M < 1 || !(sigma > 0.0)) return gpk_set_err(-1, "gpk_pref_predict: bad arguments");
   const int nx = m->N, np_ = m->Npad, d = m->d;

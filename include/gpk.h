@@ -72,7 +72,8 @@ typedef struct gpk_model gpk_model;
  * factors it, w = L^-1 y, nlml = w.w/2 + sum log L_ii + N log(2 pi)/2.  K and L
  * stay in HBM behind the handle.  y may be NULL (factor only; nlml_out gets
  * sum log L_ii, the reference's "logdetK" of GPpref.py:131).
- * flags: bit0 = keep an unfactored copy of K in HBM (needed by gpk_kmatvec / gpk_kgather). */
+ * flags: bit0 = keep an unfactored copy of K in HBM (needed by gpk_kmatvec / gpk_kgather);
+ *        bit1 (with bit0, y = NULL) = build and keep K only, factor nothing (gpk_class_laplace factors B instead). */
 int gpk_fit(const double* X, const double* y, int N, int d, const double* log_hyp,
             double jitter, int flags, gpk_model** handle_out, double* nlml_out);
 /* GaussianProcess.compute_prediction: GPr.py:45-54.  mean = Kzx K^-1 y,
@@ -116,6 +117,18 @@ int gpk_pref_laplace(gpk_model* h, const long long* uvi, const double* y, int np
  * pair arguments as gpk_pref_laplace. */
 int gpk_pref_predict(gpk_model* h, const long long* uvi, const double* y, int npairs, double sigma,
                      const double* f_hat, const double* Z, int M, double* mean_out, double* var_out);
+
+/* ---- binary GP classification, Laplace approximation ----------------------------------- */
+/* What GPc.py:40-55 (a non-parsing sketch citing Rasmussen eq. 3.12) and GP_classification_demo.py:5-50 head to:
+ * Rasmussen & Williams Alg. 3.1 on a handle from gpk_fit(..., flags = 3) (K built and kept, nothing factored).
+ * y in {-1,+1} (GPc.py:24-38 maps {0,1} to it), link 0 = probit (NormCDF, GPc.py:4-6), 1 = logit (GPc.py:13-14).
+ * f_inout: start / mode (N).  Stops when max|f_new - f| <= delta_f (the rule of GPpref.py:140) or after max_iter.
+ * lml_out = -a^T f/2 + sum log p(y|f) - sum log diag L_B (R&W eq. 3.32).  PARITY UNPINNED (no runnable reference). */
+int gpk_class_laplace(gpk_model* h, const double* y, int link, double* f_inout, double delta_f, int max_iter,
+                      double* lml_out, int* iters_out, double* ferr_trace /* max_iter or NULL */);
+/* R&W Alg. 3.2 at the mode: latent mean / variance and the averaged probability of class +1 at M test points. */
+int gpk_class_predict(gpk_model* h, const double* y, int link, const double* f_hat, const double* Z, int M,
+                      double* mean_out, double* var_out, double* prob_out /* or NULL */);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------- */
 /* HIP-event timings (ms) of the stages of the last gpk_fit / gpk_predict on this
