@@ -403,8 +403,9 @@ int gpk_fit(const double* X, const double* y, int N, int d, const double* log_hy
   *handle_out = nullptr;
   if ((flags & 2) && !(flags & 1)) return gpk_set_err(-1, "gpk_fit: flag 2 (K only, no factorisation) needs flag 1 (keep K)");
   if ((flags & 2) && y) return gpk_set_err(-1, "gpk_fit: flag 2 (K only) takes no targets");
+  if ((flags & 4) && (flags & 3)) return gpk_set_err(-1, "gpk_fit: flag 4 (growable) cannot be combined with keep-K / K-only");
   gpk_model* m = nullptr;
-  GPK_TRY(model_create(&m, N, d, (flags & 1) != 0));
+  GPK_TRY(model_create(&m, N, d, (flags & 1) != 0, -1, -1, (flags & 4) != 0));
   m->k_only = (flags & 2) != 0;
   hipStream_t s = G.s_main;
   int rc = decode_hyp(log_hyp, d, jitter, m);

@@ -128,10 +128,13 @@ struct gpk_model {
   bool has_y = false, keep_k = false;
   bool k_only = false;   // gpk_fit flag 2: K built and kept, nothing factored (classification factors B = I + W^1/2 K W^1/2 instead)
   bool factored = false;
+  bool growable = false;  // gpk_fit flag 4: uniform 128-wide panels (a layout that does not depend on N), dX sized for Npad points:
+                          // gpk_append extends the factor instead of refactoring
+  size_t dX_elems = 0;
   double* Lpanel(int p) const { return dL + poff[p]; }
 };
 
-int model_create(gpk_model** out, int N, int d, bool keep_k, int P = -1, int r = -1);
+int model_create(gpk_model** out, int N, int d, bool keep_k, int P = -1, int r = -1, bool growable = false);
 void model_destroy(gpk_model* m);
 int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m);
 // prediction job fused into a fit: V = Kzx L^-T is pipelined panel by panel behind the factorisation

@@ -129,7 +129,7 @@ int timers_resolve() {
 }
 
 // ------------------------------------------------------------------ model
-int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r) {
+int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool growable) {
   GPK_TRY(rt_require());
   if (N < 1) return gpk_set_err(-1, "N=%d must be >= 1", N);
   if (d < 1 || d > 32) return gpk_set_err(-1, "input dimension d=%d outside 1..32", d);
@@ -139,6 +139,8 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r) {
   int nb = G.nb;
   if (nb < 128) nb = 128;
   nb = nb / 128 * 128;
+  if (growable) nb = 128;
+  m->growable = growable;
   m->NB = nb;
   if (P < 1) { P = G.nranks; r = G.rank; } else { m->virtual_rank = true; }
   m->P = P;
@@ -150,13 +152,13 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r) {
   // the inner ones where the two-level schedule applies
   auto inner_width = [&](int rem) {
     int w = nb;
-    if (P == 1 && G.nb_auto) {
+    if (P == 1 && G.nb_auto && !growable) {
       if (rem > G.nb_big_until + G.nb_big) w = G.nb_big;
       else if (rem <= G.nb_small_from) w = G.nb_small;
     }
     return w;
   };
-  const bool two_level = (P == 1 && G.nb_auto && G.lookahead && G.nb_outer >= 256 && m->Npad >= G.outer_from);
+  const bool two_level = (P == 1 && !growable && G.nb_auto && G.lookahead && G.nb_outer >= 256 && m->Npad >= G.outer_from);
   size_t off = 0;
   for (int c0 = 0; c0 < m->Npad;) {
     const int rem = m->Npad - c0;
@@ -190,7 +192,8 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r) {
   m->keep_k = keep_k;
   const size_t np = m->Npad;
   int rc = 0;
-  rc |= dev_alloc_t(&m->dX, (size_t)N * d);
+  m->dX_elems = growable ? np * (size_t)d : (size_t)N * d;
+  rc |= dev_alloc_t(&m->dX, m->dX_elems);
   rc |= dev_alloc_t(&m->dy, np);
   rc |= dev_alloc_t(&m->dw, np);
   rc |= dev_alloc_t(&m->dK, np * (size_t)m->ldk);
@@ -212,7 +215,7 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r) {
 void model_destroy(gpk_model* m) {
   if (!m) return;
   const size_t np = m->Npad;
-  dev_free(m->dX, (size_t)m->N * m->d * 8);
+  dev_free(m->dX, m->dX_elems * 8);
   dev_free(m->dy, np * 8);
   dev_free(m->dw, np * 8);
   dev_free(m->dK, np * (size_t)m->ldk * 8);

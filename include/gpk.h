@@ -73,7 +73,8 @@ typedef struct gpk_model gpk_model;
  * stay in HBM behind the handle.  y may be NULL (factor only; nlml_out gets
  * sum log L_ii, the reference's "logdetK" of GPpref.py:131).
  * flags: bit0 = keep an unfactored copy of K in HBM (needed by gpk_kmatvec / gpk_kgather);
- *        bit1 (with bit0, y = NULL) = build and keep K only, factor nothing (gpk_class_laplace factors B instead). */
+ *        bit1 (with bit0, y = NULL) = build and keep K only, factor nothing (gpk_class_laplace factors B instead);
+ *        bit2 = growable (gpk_append): uniform 128-wide panels instead of the automatic panel schedule. */
 int gpk_fit(const double* X, const double* y, int N, int d, const double* log_hyp,
             double jitter, int flags, gpk_model** handle_out, double* nlml_out);
 /* GaussianProcess.compute_prediction: GPr.py:45-54.  mean = Kzx K^-1 y,
@@ -117,6 +118,15 @@ int gpk_pref_laplace(gpk_model* h, const long long* uvi, const double* y, int np
  * pair arguments as gpk_pref_laplace. */
 int gpk_pref_predict(gpk_model* h, const long long* uvi, const double* y, int npairs, double sigma,
                      const double* f_hat, const double* Z, int M, double* mean_out, double* var_out);
+
+/* ---- incremental data growth ---------------------------------------------------------- */
+/* GP_parameter_fit.py:62 grows its model one observation per frame (gpm.set_XY(X[0:ii+1], Y[0:ii+1])) and GPy
+ * refactors K every time.  gpk_append extends the factor of a model fitted with gpk_fit flag bit2 (4, "growable":
+ * uniform 128-wide panels) by k more points: row substitution of the new tile rows + one SYRK + the panel
+ * factorisation of the trailing (<= 128 + k)-wide block, O((128 + k) n^2) instead of n^3/3.  The handle may be
+ * replaced (a larger padded size); on a positive return (not positive definite) the OLD handle stays valid only
+ * if it was replaced, otherwise it must be freed.  nlml_out: the nlml of the grown model. */
+int gpk_append(gpk_model** handle_inout, const double* X_new, const double* y_new, int k, double* nlml_out);
 
 /* ---- binary GP classification, Laplace approximation ----------------------------------- */
 /* What GPc.py:40-55 (a non-parsing sketch citing Rasmussen eq. 3.12) and GP_classification_demo.py:5-50 head to:

@@ -173,3 +173,15 @@ def synthetic_problem(N, d, M=1024, seed=1234):
     Z = rng.random_sample((M, d))
     log_hyp = np.log([0.7] * d + [1.0, 0.1])
     return X, y, Z, log_hyp
+
+
+def gpy_regression_predict(X, Y, variance, lengthscale, noise_var, Xnew):
+    """Dense restatement of the GPy calls of GP_parameter_fit.py:30-31,52 (GPy is absent: PARITY UNPINNED; GPy's
+    documented semantics): RBF kernel variance*exp(-r^2/2), Gaussian noise; returns (mean (M,1), var of y (M,1),
+    log marginal likelihood).  Same SE arithmetic as GPr.py:99-110 with sf2 = variance, sn2 = noise_var."""
+    X = np.asarray(X, dtype=float).reshape(len(X), -1)
+    d = X.shape[1]
+    ell = np.asarray(lengthscale, dtype=float).reshape(-1) * np.ones(d)
+    lh = np.concatenate([np.log(ell), [0.5 * np.log(variance)], [0.5 * np.log(noise_var)]])
+    nlml, fz, cov = posterior_efficient(lh, X, np.asarray(Y, dtype=float).reshape(-1), np.asarray(Xnew, dtype=float).reshape(len(Xnew), -1))
+    return fz.reshape(-1, 1), (cov + noise_var).reshape(-1, 1), -nlml

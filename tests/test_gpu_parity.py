@@ -917,6 +917,138 @@ def test_gpc_demo_flow(gpk):
     assert np.corrcoef(r["prob"], r["truth"])[0, 1] > 0.5
 
 
+# ----------------------------------------------------------------------------- growing data
+@pytest.mark.parametrize("n0,steps,d", [(1, [1, 1, 1, 5], 1), (37, [1, 90, 1, 200], 2), (128, [1, 127, 1], 3),
+                                        (200, [56, 1, 1, 300], 2), (1000, [1, 24, 500], 4), (2049, [1, 1, 254, 1], 8)])
+def test_append_extends_the_factor_like_a_refit(gpk, n0, steps, d):
+    """gpk_append (rank-append Cholesky: row substitution + one SYRK + panel factorisation of the trailing block)
+    against refitting from scratch at every size -- the growth pattern of GP_parameter_fit.py:62 -- across tile
+    boundaries, in-place and re-allocated.  Same mathematics, different summation order: 1e-10; oracle: 1e-6."""
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+
+    ntot = n0 + sum(steps)
+    X, y, Z, lh = orc.synthetic_problem(ntot, d, 50)
+    lhc = np.ascontiguousarray(lh)
+    h = ctypes.c_void_p()
+    nl = ctypes.c_double()
+    X0, y0 = np.ascontiguousarray(X[:n0]), np.ascontiguousarray(y[:n0])
+    assert gpk.lib().gpk_fit(_ptr(X0), _ptr(y0), n0, d, _ptr(lhc), 0.0, 4, ctypes.byref(h), ctypes.byref(nl)) == 0, gpk.last_error()
+    n = n0
+    try:
+        for k in steps:
+            xt, yt = np.ascontiguousarray(X[n:n + k]), np.ascontiguousarray(y[n:n + k])
+            assert gpk.lib().gpk_append(ctypes.byref(h), _ptr(xt), _ptr(yt), k, ctypes.byref(nl)) == 0, gpk.last_error()
+            n += k
+            mean, var = np.empty(50), np.empty(50)
+            assert gpk.lib().gpk_predict(h, _ptr(Z), 50, _ptr(mean), _ptr(var)) == 0, gpk.last_error()
+            href, nl_ref = GPr.fit_handle(X[:n], y[:n], lh)
+            mr, vr = np.empty(50), np.empty(50)
+            assert gpk.lib().gpk_predict(href.ptr, _ptr(Z), 50, _ptr(mr), _ptr(vr)) == 0
+            assert abs(nl.value - nl_ref) <= 1e-10 * max(1.0, abs(nl_ref)), (n, nl.value, nl_ref)
+            np.testing.assert_allclose(mean, mr, rtol=0, atol=1e-9 * max(1.0, np.abs(mr).max()))
+            np.testing.assert_allclose(var, vr, rtol=0, atol=1e-9)
+        nl_o, fz_o, cov_o = orc.posterior_efficient(lh, X[:n], y[:n], Z)
+        assert abs(nl.value - nl_o) <= RTOL * abs(nl_o)
+        np.testing.assert_allclose(mean, fz_o, rtol=RTOL, atol=RTOL * np.abs(fz_o).max())
+        np.testing.assert_allclose(var, cov_o, rtol=0, atol=RTOL)
+        L = np.empty((n, n))
+        assert gpk.lib().gpk_model_get_L(h, _ptr(L)) == 0
+        np.testing.assert_allclose(L @ L.T, orc.kxx(lh, X[:n]), rtol=0, atol=1e-10)
+    finally:
+        gpk.lib().gpk_free(h)
+
+
+def test_append_refuses_models_that_cannot_grow(gpk):
+    from gptest_amd import GPr
+    from oracle import gpr_oracle as orc
+
+    X, y, _, lh = orc.synthetic_problem(300, 2, 4)
+    h, _ = GPr.fit_handle(X[:200], y[:200], lh)            # not fitted with the growable flag
+    hp = ctypes.c_void_p(h.ptr.value)
+    xt, yt = np.ascontiguousarray(X[200:]), np.ascontiguousarray(y[200:])
+    assert gpk.lib().gpk_append(ctypes.byref(hp), _ptr(xt), _ptr(yt), 100, None) < 0
+    assert "growable" in gpk.last_error()
+    # a non-finite new input makes the first new pivot fail: LAPACK-style positive return (-> LinAlgError)
+    hg = ctypes.c_void_p()
+    X0, y0 = np.ascontiguousarray(X[:150]), np.ascontiguousarray(y[:150])
+    assert gpk.lib().gpk_fit(_ptr(X0), _ptr(y0), 150, 2, _ptr(np.ascontiguousarray(lh)), 0.0, 4, ctypes.byref(hg), None) == 0
+    bad = np.array([[np.nan, 0.5]])
+    rc = gpk.lib().gpk_append(ctypes.byref(hg), _ptr(bad), _ptr(np.ascontiguousarray(y[:1])), 1, None)
+    assert rc == 151
+    with pytest.raises(np.linalg.LinAlgError):
+        gpk.check(rc, "gpk_append")
+    gpk.lib().gpk_free(hg)
+
+
+def test_gpy_compat_growing_model_flow(gpk):
+    """The GPy calls of GP_parameter_fit.py (:20-31 data and model, :52 predict, :62 set_XY with one more observation
+    per frame) through gptest_amd.gpy_compat: every frame after the first extends the factor in HBM instead of
+    refactoring, and predicts like the dense restatement.  PARITY UNPINNED (GPy absent): GPy's documented semantics."""
+    import math
+
+    from gptest_amd import gpy_compat as GPy_
+    from oracle import gpr_oracle as orc
+
+    mean_value = 3
+
+    def explore_cost_function(a, b):      # GP_parameter_fit.py:10-20 (first three bumps suffice for a test field)
+        cost = mean_value
+        cost += 10 * math.exp(-math.sqrt((a - 40) ** 2 + (b - 40) ** 2) / 16)
+        cost += 7 * math.exp(-math.sqrt((a - 10) ** 2 + (b - 90) ** 2) / 12)
+        cost += 4 * math.exp(-math.sqrt((a - 80) ** 2 + (b - 60) ** 2) / 32)
+        return cost
+
+    rng = np.random.RandomState(0)
+    N_POINTS = 200
+    X = rng.uniform(0., 100., (N_POINTS, 2))
+    Y = np.array([[explore_cost_function(a, b)] for a, b in X]) + rng.randn(N_POINTS, 1) * 0.25
+    kernel = GPy_.RBF(input_dim=2, variance=10., lengthscale=20.)
+    gpm = GPy_.GPRegression(X, Y - mean_value, kernel)
+    gpm.noise_var = 0.0625
+    Xt, Yt = np.meshgrid(np.arange(0, 100, 10), np.arange(0, 100, 10))
+    Xfull = np.vstack([Xt.ravel(), Yt.ravel()]).transpose().astype(float)
+    m_all, v_all = gpm.predict(Xfull)
+    mo, vo, ll = orc.gpy_regression_predict(X, Y - mean_value, 10., 20., 0.0625, Xfull)
+    assert m_all.shape == v_all.shape == (100, 1)
+    np.testing.assert_allclose(m_all, mo, rtol=0, atol=1e-6 * np.abs(mo).max())
+    np.testing.assert_allclose(v_all, vo, rtol=0, atol=1e-6 * 10.)
+    assert gpm.log_likelihood() == pytest.approx(ll, rel=1e-9)
+    refits0 = gpm.refits
+    for ii in range(40):                  # GP_parameter_fit.py:61-63
+        gpm.set_XY(X[0:ii + 1, :], Y[0:ii + 1] - mean_value)
+        Yfull, varYfull = gpm.predict(Xfull)
+        if ii in (0, 1, 7, 39):
+            mo, vo, ll = orc.gpy_regression_predict(X[:ii + 1], Y[:ii + 1] - mean_value, 10., 20., 0.0625, Xfull)
+            np.testing.assert_allclose(Yfull, mo, rtol=0, atol=1e-6 * max(1.0, np.abs(mo).max()))
+            np.testing.assert_allclose(varYfull, vo, rtol=0, atol=1e-6 * 10.)
+            assert gpm.log_likelihood() == pytest.approx(ll, rel=1e-9, abs=1e-9)
+    assert gpm.X.shape == (40, 2)
+    assert gpm.refits == refits0 + 1 and gpm.appended_points == 39   # one refit (200 -> 1 point), then 39 appends
+    np.testing.assert_allclose(kernel.K(X[:30]), 10. * np.exp(-0.5 * orc.squared_distance(X[:30] / 20., X[:30] / 20.)), rtol=1e-12)
+
+
+def test_gpy_compat_optimize_uses_the_device_gradient(gpk):
+    from gptest_amd import gpy_compat as GPy_
+    from oracle import gpr_oracle as orc
+
+    X, y, Z, _ = orc.synthetic_problem(400, 2, 10, seed=5)
+    gpm = GPy_.GPRegression(X, y.reshape(-1, 1), GPy_.RBF(2, variance=1., lengthscale=1.))
+    ll0 = gpm.log_likelihood()
+    th = gpm._theta()
+    f0, g = gpm._objective(th)
+    for i in range(len(th)):              # central differences of the device nlml pin the chain rule
+        e = np.zeros(len(th)); e[i] = 1e-5
+        fp, _ = gpm._objective(th + e)
+        fm, _ = gpm._objective(th - e)
+        assert g[i] == pytest.approx((fp - fm) / 2e-5, rel=2e-5, abs=1e-6)
+    gpm._objective(th)
+    gpm.optimize(max_iters=200)
+    assert gpm.log_likelihood() > ll0 + 10.0
+    assert 0.003 < gpm.noise_var < 0.03     # the data carry 0.1^2 of noise
+    assert "GP regression" in str(gpm)
+
+
 # ----------------------------------------------------------------------------- retained alternative code paths
 @pytest.mark.parametrize("opts", [
     {"leaf_algo": 0},                                    # column-by-column leaf elimination
