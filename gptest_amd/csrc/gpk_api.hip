@@ -941,6 +941,7 @@ extern "C" int gpk_test_dist_posterior(const double* X, const double* y, int N, 
   return rc;
 }
 
+#ifndef GPK_HOSTSIM  // device-only probes (MFMA builtins, hardware registers): not part of the host-side sanitizer build
 // ---------------------------------------------------------------- micro-benchmarks
 typedef double d4_t __attribute__((ext_vector_type(4)));
 template <int NACC>
@@ -1270,3 +1271,4 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
 }
 
 }  // extern "C"
+#endif  // GPK_HOSTSIM
