@@ -78,6 +78,7 @@ def _bind(l):
         "gpk_bench_leaf": (i, [i, i, dp]),
         "gpk_bench_leaf_contended": (i, [i, dp, dp]),
         "gpk_bench_chain_step": (i, [i, i, i, dp, dp]),
+        "gpk_bench_clock_under_load": (i, [i, i, i, i, dp, dp]),
         "gpk_debug_cu_masks": (i, [i, ctypes.POINTER(ctypes.c_uint), i, ctypes.POINTER(ctypes.c_uint)]),
     }
     for name, (res, args) in sig.items():

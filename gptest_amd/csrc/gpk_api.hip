@@ -41,7 +41,7 @@ int gpk_init(int device) {
   bool masked = false;
   if (want_reserve) {
     const int words = (ncu + 31) / 32;
-    std::vector<uint32_t> m_all(words, 0u), m_leaf(words, 0u);
+    std::vector<uint32_t> m_all(words, 0u);
     for (int c = 0; c < ncu; ++c) m_all[c / 32] |= (1u << (c % 32));
     // One reserved CU PER XCD: a queue whose mask names CUs of a single XCD is still dispatched round-robin over
     // all 8 XCDs, and on the XCDs where its mask is empty the runtime lets it use every CU (measured with
@@ -57,7 +57,6 @@ int gpk_init(int device) {
       for (int x = 0; x < 8; ++x) {
         const int r = (mode == 0) ? (ncu - 8 * (j + 1) + x) : ((x + 1) * (ncu / 8) - 1 - j);
         m_all[r / 32] &= ~(1u << (r % 32));
-        m_leaf[r / 32] |= (1u << (r % 32));
       }
     G.ncu_reserved = 8 * per_xcd;
     hipError_t e1 = hipExtStreamCreateWithCUMask(&G.s_main, words, m_all.data());
@@ -71,16 +70,11 @@ int gpk_init(int device) {
     hipError_t e2 = e1 != hipSuccess ? e1
                     : panel_prio     ? hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, phi)
                                      : hipExtStreamCreateWithCUMask(&G.s_panel, words, m_all.data());
-    // The leaf runs on the panel chain's stream (leaf_direct_rows): that stream is unmasked, and the CUs the update
-    // stream's mask leaves out are where its 1024-thread workgroup finds room.  A leaf stream of its own (masked to
-    // those CUs, two event hops per leaf) is only created on request: GPK_LEAF_STREAM=1.
-    const char* env_ls = getenv("GPK_LEAF_STREAM");
-    const bool leaf_stream = env_ls && env_ls[0] == '1';
-    hipError_t e3 = e2;
-    if (e2 == hipSuccess) {
-      if (leaf_stream) e3 = hipExtStreamCreateWithCUMask(&G.s_leaf, words, m_leaf.data());
-      else G.s_leaf = G.s_panel;
-    }
+    // The leaf runs on the panel chain's stream: that stream is unmasked, and the CUs the update stream's mask leaves
+    // out are where its 1024-thread workgroup finds room.  (Round 1 also had a leaf stream of its own, masked to those
+    // CUs: two event hops per leaf cost more than the mask bought.)  The tile pipeline's second chain stream (s_rows)
+    // only exists while option tail_rows > 0: an idle fourth stream costs 4 % at N = 4096 (3.18 -> 3.32 ms, A/B on one box).
+    hipError_t e3 = e2;  // (s_rows is created when the tile pipeline is switched on: option tail_rows)
     if (e3 == hipSuccess) {
       // s_pred (forward substitutions pipelined behind the panels): priority instead of a mask, otherwise its
       // kernels queue behind thousands of trailing-update workgroups and the whole backlog (2.7 ms measured)
@@ -101,9 +95,9 @@ int gpk_init(int device) {
       (void)hipGetLastError();
       if (G.s_main) (void)hipStreamDestroy(G.s_main);
       if (G.s_pred && G.s_pred != G.s_panel) (void)hipStreamDestroy(G.s_pred);
-      if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf);
+      if (G.s_rows) (void)hipStreamDestroy(G.s_rows);
       if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
-      G.s_main = G.s_panel = G.s_leaf = G.s_pred = nullptr;
+      G.s_main = G.s_panel = G.s_rows = G.s_pred = nullptr;
     }
   }
   int lo = 0, hi = 0;
@@ -112,15 +106,9 @@ int gpk_init(int device) {
     GPK_HIP(hipStreamCreateWithPriority(&G.s_main, hipStreamNonBlocking, lo));
     GPK_HIP(hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, hi));
     GPK_HIP(hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, lo));
-    G.s_leaf = G.s_panel;
   }
   G.cu_reserved = masked;
   G.ncu = masked ? ncu - G.ncu_reserved : ncu;
-  for (int i = 0; i < 64; ++i) {
-    hipEvent_t e;
-    GPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    G.ev_ring.push_back(e);
-  }
   G.device = device;
   {
     // Touch every stream once.  The runtime builds a stream's hardware queue lazily; destroying a CU-masked
@@ -130,7 +118,7 @@ int gpk_init(int device) {
     if (!(env_nt && env_nt[0] == '1')) {
       unsigned long long* dtouch = nullptr;
       GPK_HIP(hipMalloc((void**)&dtouch, 64));
-      hipStream_t all[4] = {G.s_main, G.s_panel, G.s_leaf, G.s_pred};
+      hipStream_t all[4] = {G.s_main, G.s_panel, nullptr, G.s_pred};
       for (int i = 0; i < 4; ++i)
         if (all[i]) GPK_TRY(launch_stamp(dtouch + i, all[i]));
       GPK_HIP(hipDeviceSynchronize());
@@ -173,16 +161,14 @@ void gpk_shutdown(void) {
   SD_STEP("destroy s_pred", if (G.s_pred && G.s_pred != G.s_panel) (void)hipStreamDestroy(G.s_pred));
   G.s_pred = nullptr;
   if (!old_order) SD_STEP("destroy s_main", if (G.s_main) (void)hipStreamDestroy(G.s_main));
-  SD_STEP("destroy s_leaf", if (G.s_leaf && G.s_leaf != G.s_panel) (void)hipStreamDestroy(G.s_leaf));
+  SD_STEP("destroy s_rows", if (G.s_rows) (void)hipStreamDestroy(G.s_rows));
   SD_STEP("destroy s_panel", if (G.s_panel) (void)hipStreamDestroy(G.s_panel));
   SD_STEP("destroy events", {
-    for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
     for (hipEvent_t e : G.ev_dep_free) (void)hipEventDestroy(e);
   });
 #undef SD_STEP
-  G.ev_ring.clear();
   G.ev_dep_free.clear();
-  G.s_main = G.s_panel = G.s_leaf = nullptr;
+  G.s_main = G.s_panel = G.s_rows = nullptr;
   G.inited = false;
 }
 
@@ -226,8 +212,17 @@ int gpk_set_option(const char* key, double value) {
     g_gemm_variant = (int)value;
   } else if (k == "xcd_sq") {
     G.xcd_sq = (int)value;
-  } else if (k == "leaf_direct_rows") {
-    G.leaf_direct_rows = (int)value;
+  } else if (k == "tail_rows") {
+    G.tail_rows = (int)value;
+    if (G.inited && G.tail_rows > 0 && !G.s_rows) {
+      int lo_ = 0, hi_ = 0;
+      GPK_HIP(hipDeviceGetStreamPriorityRange(&lo_, &hi_));
+      GPK_HIP(hipStreamCreateWithPriority(&G.s_rows, hipStreamNonBlocking, hi_));
+    } else if (G.inited && G.tail_rows <= 0 && G.s_rows) {
+      GPK_HIP(hipDeviceSynchronize());
+      GPK_HIP(hipStreamDestroy(G.s_rows));
+      G.s_rows = nullptr;
+    }
   } else if (k == "stamps") {
     G.stamps = (int)value;
   } else if (k == "pred_small_below") {
@@ -275,7 +270,6 @@ double gpk_get_option(const char* key) {
   if (k == "outer_from") return G.outer_from;
   if (k == "nb_outer") return G.nb_outer;
   if (k == "xcd_sq") return G.xcd_sq;
-  if (k == "leaf_direct_rows") return G.leaf_direct_rows;
   if (k == "pred_small_below") return G.pred_small_below;
   if (k == "small_tile_below") return G.small_tile_below;
   if (k == "pair_update") return G.pair_update;
@@ -283,6 +277,8 @@ double gpk_get_option(const char* key) {
   if (k == "fuse_predict") return G.fuse_predict;
   if (k == "solve_gemm_above") return G.solve_gemm_above;
   if (k == "stamps") return G.stamps;
+  if (k == "tail_rows") return G.tail_rows;
+  if (k == "potrf_tail_from") { extern int g_potrf_tail_from; return g_potrf_tail_from; }
   if (k == "test_gemm_k1") return G.test_gemm_k1;
   if (k == "leaf_algo") { extern int g_leaf_algo; return g_leaf_algo; }
   if (k == "gemm_variant") { extern int g_gemm_variant; return g_gemm_variant; }
@@ -452,12 +448,8 @@ int gpk_fit_predict(const double* X, const double* y, int N, int d, const double
   if (!rc && hipMemcpyAsync(dZ, Z, (size_t)M * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) rc = gpk_set_err(-2, "H2D failed");
   if (!rc) {
     if (m->P == 1) {
-      FusedPredict fp{dZ, M, Mpad, dR, dV, dmv, dmv + Mpad};
-      rc = fit_device(m, &fp);
-      if (!rc && (hipMemcpyAsync(mean_out, dmv, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                  hipMemcpyAsync(var_out, dmv + Mpad, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                  hipStreamSynchronize(s) != hipSuccess))
-        rc = gpk_set_err(-2, "fit_predict: result read-back failed");
+      FusedPredict fp{dZ, M, Mpad, dR, dV, dmv, dmv + Mpad, mean_out, var_out};
+      rc = fit_device(m, &fp);  // reads mean / var back together with the scalars
     } else {
       rc = fit_device(m);
       if (!rc) rc = predict_sharded(m, dZ, M, mean_out, var_out);
@@ -705,12 +697,9 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
         }
         if (m->P == 1) {
           // fused: the prediction solve is pipelined behind the factorisation (one K build, one Cholesky)
-          FusedPredict fp{dZ, M, Mpad1, dR1, dV1, dmv1, dmv1 + Mpad1};
-          rc = fit_device(m, &fp);  // includes the scalar read-back (the result of compute_likelihood)
+          FusedPredict fp{dZ, M, Mpad1, dR1, dV1, dmv1, dmv1 + Mpad1, hm.data(), hv.data()};
+          rc = fit_device(m, &fp);  // includes the read-back of nlml, mean and variance (one synchronisation)
           if (rc) break;
-          if (hipMemcpyAsync(hm.data(), dmv1, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
-              hipMemcpyAsync(hv.data(), dmv1 + Mpad1, (size_t)M * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
-              hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "bench: result read-back failed"); break; }
         } else {
           rc = fit_device(m);
           if (rc) break;
@@ -1065,7 +1054,7 @@ int gpk_debug_cu_masks(int nmain, unsigned* ids_main, int nleaf, unsigned* ids_l
   GPK_TRY(dev_alloc_t(&d1, (size_t)2 * nmain));
   GPK_TRY(dev_alloc_t(&d2, (size_t)2 * nleaf));
   hipLaunchKernelGGL(whoami_kernel, dim3(nmain), dim3(256), 0, G.s_main, d1, 200);
-  hipLaunchKernelGGL(whoami_kernel, dim3(nleaf), dim3(1024), 0, G.s_leaf ? G.s_leaf : G.s_main, d2, 50);
+  hipLaunchKernelGGL(whoami_kernel, dim3(nleaf), dim3(1024), 0, G.s_panel ? G.s_panel : G.s_main, d2, 50);
   GPK_HIP(hipDeviceSynchronize());
   std::vector<unsigned> h1(2 * nmain), h2(2 * nleaf);
   GPK_HIP(hipMemcpy(h1.data(), d1, h1.size() * 4, hipMemcpyDeviceToHost));
@@ -1086,7 +1075,7 @@ int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended) {
   const int dbg = reps >> 16;  // upper bits: leaf dbg_skip mode
   reps &= 0xffff;
   GPK_TRY(rt_require());
-  hipStream_t sl = G.s_leaf ? G.s_leaf : G.s_main, sm = G.s_main;
+  hipStream_t sl = G.s_panel ? G.s_panel : G.s_main, sm = G.s_main;
   double *dA = nullptr, *dL = nullptr, *dD = nullptr, *gA = nullptr, *gC = nullptr;
   int* dinfo = nullptr;
   const int gm = 8192, gk = 256;
@@ -1131,6 +1120,56 @@ int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended) {
   (void)hipEventDestroy(e1);
   dev_free(dA, 128 * 128 * 8); dev_free(dL, 128 * 128 * 8); dev_free(dD, 128 * 128 * 8); dev_free(dinfo, 16);
   dev_free(gA, (size_t)gm * gk * 8); dev_free(gC, (size_t)gm * gm * 8);
+  return 0;
+}
+
+// Is the chip clock-throttled under the sustained trailing update?  One wave on the panel-chain stream measures the
+// shader clock (s_memtime ticks per s_memrealtime tick x 100 MHz) over ~0.2 ms, `nsamp` times, while the update
+// stream runs `nbig` back-to-back lower updates (m x m, K = k).  ghz_out[0] = idle clock, [1..nsamp] under load.
+__global__ void clock_probe_kernel(unsigned long long* out, int spin) {
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(16);
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+int gpk_bench_clock_under_load(int m, int k, int nbig, int nsamp, double* ghz_out, double* tflops_out) {
+  GPK_TRY(rt_require());
+  hipStream_t sm = G.s_main, sp = G.s_panel;
+  Scratch sc;
+  double *gA = nullptr, *gC = nullptr;
+  unsigned long long* dclk = nullptr;
+  GPK_TRY(sc.get(&gA, (size_t)m * k));
+  GPK_TRY(sc.get(&gC, (size_t)m * m));
+  GPK_TRY(sc.get(&dclk, (size_t)2 * (nsamp + 1)));
+  std::vector<double> h((size_t)m * k);
+  unsigned long long st = 88172645463325252ull;
+  for (auto& v : h) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = ((double)(st >> 11) / 9007199254740992.0 - 0.5) * 1e-3; }
+  GPK_HIP(hipMemcpyAsync(gA, h.data(), h.size() * 8, hipMemcpyHostToDevice, sm));
+  GPK_TRY(launch_fill(gC, (size_t)m * m, 1.0, sm));
+  GPK_HIP(hipDeviceSynchronize());
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, sp, dclk, 400);
+  GPK_HIP(hipDeviceSynchronize());
+  GemmNT g{};
+  g.A = gA; g.lda = k; g.B = gA; g.ldb = k; g.C = gC; g.ldc = m; g.m = m; g.n = m; g.k = k; g.sub = 1; g.lower = 1;
+  hipEvent_t e0, e1;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  GPK_HIP(hipEventRecord(e0, sm));
+  for (int r = 0; r < nbig; ++r) GPK_TRY(launch_gemm_auto(g, sm));
+  GPK_HIP(hipEventRecord(e1, sm));
+  for (int i = 0; i < nsamp; ++i) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, sp, dclk + 2 * (i + 1), 400);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, sp, dclk + 2 * (i + 1), 4000);  // spacing; overwritten sample kept
+  }
+  GPK_HIP(hipDeviceSynchronize());
+  float ms = 0;
+  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (tflops_out) *tflops_out = (double)nbig * (double)m * m * k / (ms * 1e-3) / 1e12;
+  std::vector<unsigned long long> hc((size_t)2 * (nsamp + 1));
+  GPK_HIP(hipMemcpy(hc.data(), dclk, hc.size() * 8, hipMemcpyDeviceToHost));
+  for (int i = 0; i <= nsamp; ++i) ghz_out[i] = hc[2 * i + 1] ? (double)hc[2 * i] / (double)hc[2 * i + 1] * 0.1 : 0.0;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return 0;
 }
 

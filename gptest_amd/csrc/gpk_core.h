@@ -20,11 +20,9 @@ struct Runtime {
   int device = 0;
   hipStream_t s_main = nullptr, s_panel = nullptr;
   hipStream_t s_pred = nullptr;   // y and prediction substitutions pipelined behind the factorisation (fused fit+predict)
-  hipStream_t s_leaf = nullptr;   // CU-masked stream owning one reserved CU for the 1-workgroup leaf kernels
+  hipStream_t s_rows = nullptr;   // tile pipeline of the chain-bound tail: the full-height panel GEMMs (s_panel keeps the leaves)
   bool cu_reserved = false;
   int ncu_reserved = 8;
-  std::vector<hipEvent_t> ev_ring;
-  size_t ev_ring_pos = 0;
   std::map<size_t, std::vector<void*>> pool;
   size_t pool_bytes = 0;
   // options
@@ -38,9 +36,11 @@ struct Runtime {
   // inner level.  Active for Npad >= outer_from while more than outer_until columns remain; 0 = one level.
   int nb_outer = 2048, outer_from = 1 << 30, outer_until = 4096;  // off by default: measured no gain
   int lookahead = 1;
+  // tile pipeline (potrf_tail) for the chain-bound last tail_rows columns (needs 128-wide panels there: nb_small_from);
+  // 0 = the panel-level look-ahead everywhere
+  int tail_rows = 0;
   double last_potrf_enqueue_ms = 0.0, last_pipe_enqueue_ms = 0.0;  // host time spent queueing the last factorisation
   int timing = 0;
-  int leaf_direct_rows = 5120;  // leaf goes on the chain stream (no reserved-CU hop) once this few rows remain
   int stamps = 0;  // diagnostic: device-side progress stamps per panel (gpk_get_option("stamp_lag_*"))
   unsigned long long* dstamps = nullptr;
   std::vector<unsigned long long> hstamps;
@@ -141,6 +141,7 @@ int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m);
 struct FusedPredict {
   const double* dZ; int M, Mpad;
   double *dR, *dV, *dmean, *dvar;
+  double *h_mean = nullptr, *h_var = nullptr;  // host destinations: read back together with the scalars (one sync)
 };
 int fit_device(gpk_model* m, const FusedPredict* fp = nullptr);  // K build + potrf + w + scalars (inputs resident)
 extern int g_potrf_lookahead_used;  // 1 if the last potrf_device recorded per-panel events in m->ev[0..nP)

@@ -5,6 +5,7 @@
 
 Runtime G;
 int g_potrf_lookahead_used = 0;
+int g_potrf_tail_from = -1;  // first panel the last factorisation sent through the tile pipeline (-1: none)
 extern "C" int gpk_comm_allreduce_max(double* inout, int n);
 static thread_local std::string g_err = "";
 
@@ -251,32 +252,6 @@ int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m) {
 // sub-panels inside a panel.  L goes to its own panel-packed storage (panel p =
 // rows c0.. x w, ld = w): compact operands for every later kernel and no in-place hazard
 // in the panel solve.  Replaces np.linalg.cholesky (GPr.py:62, GPpref.py:128).
-static hipEvent_t ring_event() {
-  hipEvent_t e = G.ev_ring[G.ev_ring_pos % G.ev_ring.size()];
-  G.ev_ring_pos++;
-  return e;
-}
-
-// The 1-workgroup leaf goes to the stream that owns the reserved CU; `s` is fenced around it.
-static int launch_leaf(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, hipStream_t s,
-                       int rows_left) {
-  // The reserved-CU stream costs two cross-stream hops (~13 us each).  Near the end of the factorisation the
-  // trailing updates no longer fill the chip, an empty CU is always at hand, and the leaf stays on the chain stream.
-  hipStream_t sl = (G.cu_reserved && G.s_leaf && rows_left > G.leaf_direct_rows) ? G.s_leaf : s;
-  if (sl != s) {
-    hipEvent_t e = ring_event();
-    GPK_HIP(hipEventRecord(e, s));
-    GPK_HIP(hipStreamWaitEvent(sl, e, 0));
-  }
-  GPK_TRY(launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, sl));
-  if (sl != s) {
-    hipEvent_t e = ring_event();
-    GPK_HIP(hipEventRecord(e, sl));
-    GPK_HIP(hipStreamWaitEvent(s, e, 0));
-  }
-  return 0;
-}
-
 int factor_panel(gpk_model* m, int p, hipStream_t s) {
   const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
   const long ldk = m->ldk, ld = m->pld[p];
@@ -297,7 +272,7 @@ int factor_panel(gpk_model* m, int p, hipStream_t s) {
       GPK_TRY(launch_gemm_nt(g, false, s));
     }
     double* Dt = m->dDinv + (long)(cs / 128) * 128 * 128;
-    GPK_TRY(launch_leaf(Acol, ldk, Lp + (long)ro * ld + sb * 128, ld, Dt, m->dinfo, cs, s, h - ro));
+    GPK_TRY(launch_potf2_trtri_128(Acol, ldk, Lp + (long)ro * ld + sb * 128, ld, Dt, m->dinfo, cs, 0, s));
     if (h - ro - 128 > 0) {
       // L[cs+128:, sub-panel] = A[cs+128:, cs:cs+128] * Dinv^T
       GemmNT g{};
@@ -478,6 +453,118 @@ static int potrf_device_paired(gpk_model* m, const std::function<int(int)>* afte
   return 0;
 }
 
+// ------------------------------------------------------------------ tile pipeline for the chain-bound tail
+// Where few columns remain the factorisation is a chain of dependent latency-bound kernels: per 128 columns a leaf
+// (50 us) and two or three full-height skinny GEMMs, each of which waits for CU slots next to the running update
+// (25-35 us under load instead of 8).  This schedule takes the full-height GEMMs OFF the chain.  With 128-wide panels
+// and tile rows r = p+1, p+2, ... below diagonal tile p, step p is split over three streams (event names in brackets):
+//   s_panel (critical):  leaf(p)  [leaf]                                     needs tile (p,p) final
+//                        T(p): L(p+1,p) = A(p+1,p) Dinv(p)^T;  A(p+1,p+1) -= L(p+1,p) L(p+1,p)^T   [tt]
+//                              two one-tile GEMMs; needs LAnear(p-1)
+//   s_rows:              SOLVE(p): L(i,p) = A(i,p) Dinv(p)^T, i >= p+2       needs leaf(p)              [panel]
+//                        LAnear(p): A(i, p+1..p+2) -= L(i,p) L(p+1..p+2, p)^T, i >= p+2   needs T(p)    [near]
+//                        LAfar(p):  A(i, p+3)      -= L(i,p) L(p+3,p)^T,       i >= p+3   needs REST(p-1)
+//   s_main:              REST(p): lower square from tile (p+4,p+4), the bulk   needs SOLVE(p)             [rest]
+// so the chain per step is leaf + two one-tile kernels, and a column is written, in this order, by REST (up to four
+// steps earlier), LAfar, LAnear and T: every hazard is covered by stream order on s_rows plus the three waits above.
+// Each element receives the same rank-128 updates in the same order as in the panel-level schedule with 128-wide
+// panels, so the factor is bit-identical to it (tests).  `ev_prev_rest`: what plays REST(p_first - 1).
+static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const std::function<int(int)>* after_panel) {
+  hipStream_t sm = G.s_main, sc = G.s_panel, sr = G.s_rows;
+  const int nP = m->nP, np_ = m->Npad;
+  const long ldk = m->ldk;
+  hipEvent_t* ev_panel = m->ev.data();
+  hipEvent_t* ev_leaf = m->ev.data() + 3 * nP + 6;
+  hipEvent_t* ev_tt = m->ev.data() + 4 * nP + 6;
+  hipEvent_t* ev_near = m->ev.data() + 5 * nP + 6;
+  hipEvent_t* ev_rest = m->ev.data() + 6 * nP + 6;
+  GPK_HIP(hipStreamWaitEvent(sr, ev_prev_rest, 0));  // s_rows joins here; its first kernels also wait for a leaf
+  for (int p = p_first; p < nP; ++p) {
+    const int c0 = m->pc0[p], h = np_ - c0;
+    const long ld = m->pld[p];
+    double* Lp = m->Lpanel(p);
+    double* Acol = m->dK + (long)c0 * ldk + c0;
+    double* Dt = m->dDinv + (long)(c0 / 128) * 128 * 128;
+    hipEvent_t rest_before = (p > p_first) ? ev_rest[p - 1] : ev_prev_rest;
+    // ---- critical stream
+    GPK_TRY(launch_potf2_trtri_128(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, 0, sc));
+    GPK_HIP(hipEventRecord(ev_leaf[p], sc));
+    if (h > 128) {
+      if (p > p_first) GPK_HIP(hipStreamWaitEvent(sc, ev_near[p - 1], 0));
+      GemmNT t1{};  // L(p+1,p) = A(p+1,p) Dinv^T
+      t1.A = Acol + (long)128 * ldk; t1.lda = ldk;
+      t1.B = Dt; t1.ldb = 128;
+      t1.C = Lp + (long)128 * ld; t1.ldc = ld;
+      t1.m = 128; t1.n = 128; t1.k = 128; t1.sub = 0;
+      GPK_TRY(launch_gemm_nt(t1, false, sc));
+      GemmNT t2{};  // A(p+1,p+1) -= L(p+1,p) L(p+1,p)^T
+      t2.A = Lp + (long)128 * ld; t2.lda = ld;
+      t2.B = t2.A; t2.ldb = ld;
+      t2.C = Acol + (long)128 * ldk + 128; t2.ldc = ldk;
+      t2.m = 128; t2.n = 128; t2.k = 128; t2.sub = 1; t2.lower = 1;
+      GPK_TRY(launch_gemm_nt(t2, false, sc));
+      GPK_HIP(hipEventRecord(ev_tt[p], sc));
+    }
+    // ---- full-height panel GEMMs
+    GPK_HIP(hipStreamWaitEvent(sr, ev_leaf[p], 0));
+    if (h > 256) {
+      GemmNT g{};  // SOLVE(p): rows from tile p+2
+      g.A = Acol + (long)256 * ldk; g.lda = ldk;
+      g.B = Dt; g.ldb = 128;
+      g.C = Lp + (long)256 * ld; g.ldc = ld;
+      g.m = h - 256; g.n = 128; g.k = 128; g.sub = 0;
+      GPK_TRY(launch_gemm_nt(g, false, sr));
+    }
+    if (h > 128) GPK_HIP(hipStreamWaitEvent(sr, ev_tt[p], 0));
+    GPK_HIP(hipEventRecord(ev_panel[p], sr));  // every row of panel p is in place
+    if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sr));
+    if (after_panel) GPK_TRY((*after_panel)(p));
+    if (h > 256) {
+      GemmNT g{};  // LAnear(p): tile columns p+1, p+2, rows from tile p+2
+      g.A = Lp + (long)256 * ld; g.lda = ld;
+      g.B = Lp + (long)128 * ld; g.ldb = ld;
+      g.C = Acol + (long)256 * ldk + 128; g.ldc = ldk;
+      g.m = h - 256; g.n = std::min(256, h - 128); g.k = 128; g.sub = 1;
+      GPK_TRY(launch_gemm_nt(g, false, sr));
+    }
+    GPK_HIP(hipEventRecord(ev_near[p], sr));
+    if (h > 384) {
+      GPK_HIP(hipStreamWaitEvent(sr, rest_before, 0));
+      GemmNT g{};  // LAfar(p): tile column p+3, rows from tile p+3
+      g.A = Lp + (long)384 * ld; g.lda = ld;
+      g.B = g.A; g.ldb = ld;
+      g.C = Acol + (long)384 * ldk + 384; g.ldc = ldk;
+      g.m = h - 384; g.n = 128; g.k = 128; g.sub = 1; g.lower = 1;
+      GPK_TRY(launch_gemm_nt(g, false, sr));
+    }
+    // ---- bulk
+    GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
+    if (h > 512) {
+      const int r1 = c0 + 512;
+      const long nt = (np_ - r1) / 128;
+      const char* tname = (nt * (nt + 1) / 2 < G.small_tile_below) ? "trailing_small" : "trailing";
+      timer_begin(tname, sm, (double)(np_ - r1) * (np_ - r1) * 128);
+      GPK_TRY(panel_update(m, p, r1, r1, np_ - r1, 1, sm));
+      timer_end(tname, sm);
+    }
+    GPK_HIP(hipEventRecord(ev_rest[p], sm));
+  }
+  // join: everything after potrf runs on s_main
+  GPK_HIP(hipStreamWaitEvent(sm, ev_panel[nP - 1], 0));
+  GPK_HIP(hipStreamWaitEvent(sm, ev_near[nP - 1], 0));
+  if (nP - 1 > p_first || true) GPK_HIP(hipStreamWaitEvent(sm, ev_leaf[nP - 1], 0));
+  return 0;
+}
+
+// first outer panel of the tile-pipeline tail (nO: no tail): from there on every panel is a single 128-wide one
+static int tail_first_panel(const gpk_model* m) {
+  if (!G.tail_rows || !G.s_rows || m->P != 1) return m->nO;
+  int o = m->nO;
+  while (o > 0 && m->ow[o - 1] == 128 && m->oend[o - 1] - m->ofirst[o - 1] == 1 && m->Npad - m->oc0[o - 1] <= G.tail_rows) --o;
+  if (m->nO - o < 4) return m->nO;  // not worth a stream hand-over
+  return o;
+}
+
 // Right-looking with one panel of look-ahead: while the big SYRK of panel p runs on s_main, the
 // high-priority s_panel stream updates block column p+1 and factors panel p+1, so the latency-bound
 // leaf/panel kernels leave the critical path.
@@ -507,9 +594,10 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   // (N = 4096: 309 -> 318 posteriors/s, N = 8192: +2 %).  From N = 16384 on they lose: the K-doubled far update does
   // run faster (50 vs 44.5 TFLOP/s) but the three narrow updates per pair it needs (16 % of the flops) cost more
   // than that (N = 16384: 38.1-38.5 vs 36.9-37.05 ms, N = 32768: 241.8 vs 231.9).  1: only up to 8192, 2: always.
-  if (nP >= 6 && m->nO == nP && (G.pair_update == 2 || (G.pair_update == 1 && m->Npad <= 8192)))
+  g_potrf_tail_from = -1;
+  if (nP >= 6 && m->nO == nP && tail_first_panel(m) == m->nO && (G.pair_update == 2 || (G.pair_update == 1 && m->Npad <= 8192)))
     return potrf_device_paired(m, after_panel);
-  GPK_TRY(model_events(m, 3 * nP + 6));
+  GPK_TRY(model_events(m, 7 * nP + 8));
   g_potrf_lookahead_used = 1;
   hipEvent_t* ev_panel = m->ev.data();        // inner panel p factored (recorded on s_panel)
   hipEvent_t* ev_trail = m->ev.data() + nP;   // rest-update of OUTER step o done (recorded on s_main)
@@ -538,9 +626,31 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   // s_panel must not start before the K build queued on s_main has finished
   GPK_HIP(hipEventRecord(ev_start, sm));
   GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
+  const int o_tail = tail_first_panel(m);  // outer panels from here on go through the tile pipeline
+  g_potrf_tail_from = (o_tail < nO) ? m->ofirst[o_tail] : -1;
+  if (o_tail == 0) return potrf_tail(m, 0, ev_start, after_panel);
   GPK_TRY(factor_outer(0, sp, nullptr));
   for (int o = 0; o < nO; ++o) {
     const int r0 = m->oc0[o] + m->ow[o];             // first row/col of the trailing matrix
+    if (o_tail < nO && o + 1 == o_tail) {
+      // hand-over to the tile pipeline: its first leaf needs tile column o+1, its first T / LAnear the two columns
+      // after it, so the chain stream applies this panel to three tile columns, the update stream to the rest
+      // (which then stands for REST(first tail panel - 1))
+      const int w_la = std::min(384, np_ - r0);
+      if (o > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[o - 1], 0));
+      GPK_TRY(outer_update(m, o, r0, r0, w_la, 1, sp));
+      GPK_HIP(hipStreamWaitEvent(sm, ev_panel[m->oend[o] - 1], 0));
+      const int r1 = r0 + w_la;
+      if (np_ - r1 > 0) {
+        const long nt = (np_ - r1) / 128;
+        const char* tname = (nt * (nt + 1) / 2 < G.small_tile_below) ? "trailing_small" : "trailing";
+        timer_begin(tname, sm, (double)(np_ - r1) * (np_ - r1) * m->ow[o]);
+        GPK_TRY(outer_update(m, o, r1, r1, np_ - r1, 1, sm));
+        timer_end(tname, sm);
+      }
+      GPK_HIP(hipEventRecord(ev_trail[o], sm));
+      return potrf_tail(m, m->ofirst[o_tail], ev_trail[o], after_panel);
+    }
     const int wn = (o + 1 < nO) ? m->ow[o + 1] : 0;  // width of the next block column
     const int w1 = (o + 1 < nO) ? m->pw[m->ofirst[o + 1]] : 0;  // ... of its first inner panel: the look-ahead column
     if (o + 1 < nO) {
@@ -963,6 +1073,8 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   int hinfo = 0;
   GPK_HIP(hipMemcpyAsync(hs, m->dscal, 16, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s));
+  if (fp && fp->h_mean) GPK_HIP(hipMemcpyAsync(fp->h_mean, fp->dmean, (size_t)fp->M * 8, hipMemcpyDeviceToHost, s));
+  if (fp && fp->h_var) GPK_HIP(hipMemcpyAsync(fp->h_var, fp->dvar, (size_t)fp->M * 8, hipMemcpyDeviceToHost, s));
   if (G.stamps && G.dstamps) GPK_HIP(hipMemcpyAsync(G.hstamps.data(), G.dstamps, 1024 * 8, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipStreamSynchronize(s));
   m->info = hinfo;

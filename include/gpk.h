@@ -168,6 +168,8 @@ int gpk_test_dist_fit(const double* X, int N, int d, const double* log_hyp, doub
  * nlml_out[P], mean_out / var_out [P][M] = what every rank ends up with. */
 int gpk_test_dist_posterior(const double* X, const double* y, int N, int d, const double* log_hyp, const double* Z,
                             int M, int P, double* nlml_out, double* mean_out, double* var_out);
+/* probe: shader clock (GHz) sampled on the panel stream while the update stream runs nbig lower updates (m, K = k). */
+int gpk_bench_clock_under_load(int m, int k, int nbig, int nsamp, double* ghz_out, double* tflops_out);
 /* probe: us per step of [leaf + nsmall GEMMs of small_m x 128 x 128] on the panel-chain stream, alone / under load. */
 int gpk_bench_chain_step(int reps, int nsmall, int small_m, double* us_alone, double* us_contended);
 /* device-resident timing of the kernel-matrix builder (mode 0 SE, 1 squared distance, 2 stores only). */

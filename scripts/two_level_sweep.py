@@ -26,8 +26,17 @@ def run(N, d, M, steps=6, warmup=2):
 
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+D = 8 if N > 4096 else 4
 configs = [dict(nb_outer=0)]
-if len(sys.argv) > 2 and sys.argv[2] == "short":
+if len(sys.argv) > 2 and sys.argv[2] == "tail":
+    for t in (2048, 4096, 6144, 8192, 12288):
+        configs.append(dict(tail_rows=t, nb_small_from=t))
+    configs.append(dict(tail_rows=1 << 30, nb_small_from=1 << 30))
+elif len(sys.argv) > 2 and sys.argv[2] == "panels":
+    for big, until in [(512, 4096), (512, 6144), (512, 12288), (1024, 8192), (1024, 4096), (768, 6144)]:
+        for small_from in (2048, 4096):
+            configs.append(dict(nb_big=big, nb_big_until=until, nb_small_from=small_from))
+elif len(sys.argv) > 2 and sys.argv[2] == "short":
     configs += [dict(nb_outer=1024, outer_until=4096, outer_from=8192), dict(nb_outer=2048, outer_until=4096, outer_from=8192),
                 dict(nb_outer=2048, outer_until=8192, outer_from=8192),
                 dict(nb_outer=2048, outer_until=4096, outer_from=8192, nb_big_until=1 << 30)]
@@ -40,12 +49,12 @@ else:
                 dict(nb_outer=1536, outer_until=4096, outer_from=8192),
                 dict(nb_outer=3072, outer_until=4096, outer_from=8192)]
 print("GPK_RESERVE_PER_XCD=%s GPU_MAX_HW_QUEUES=%s" % (os.environ.get("GPK_RESERVE_PER_XCD"), os.environ.get("GPU_MAX_HW_QUEUES")), flush=True)
-defaults = {k: _lib.get_option(k) for k in ("nb_outer", "outer_until", "outer_from", "nb_big_until", "nb_big")}
+defaults = {k: _lib.get_option(k) for k in ("nb_outer", "outer_until", "outer_from", "nb_big_until", "nb_big", "tail_rows", "nb_small_from")}
 for cfg in configs:
     for k, v in defaults.items():
         _lib.set_option(k, v)
     for k, v in cfg.items():
         _lib.set_option(k, v)
-    t, nl, tf, trms = run(N, 8, 1024)
+    t, nl, tf, trms = run(N, D, 1024, steps=(6 if N > 4096 else 40))
     print("%-70s %7.2f ms  %6.2f /s  nlml %.10f  trailing %.1f TFLOP/s (%.1f ms/step)" % (cfg, t, 1e3 / t, nl, tf, trms), flush=True)
 _lib.shutdown(watchdog_s=10.0)

@@ -145,6 +145,14 @@ int main() {
   opt("nb_outer", 512); opt("outer_from", 256); opt("outer_until", 256); opt("nb_big", 256); opt("nb_big_until", 512); opt("nb_small_from", 256);
   check_fit_predict(make_problem(1300, 3, 50), "two-level blocking");
   opt("outer_until", 0); opt("nb_outer", 768); check_fit_predict(make_problem(1100, 2, 10), "two-level blocking, 768");
+  opt("nb_outer", 0); opt("nb_small_from", 640); opt("tail_rows", 640); opt("nb_big_until", 512);
+  check_fit_predict(make_problem(1400, 2, 30), "tile pipeline after a hand-over");
+  CHECK(gpk_get_option("potrf_tail_from") > 0, "tile pipeline used after the hand-over");
+  opt("nb", 128); opt("tail_rows", 1 << 30);
+  check_fit_predict(make_problem(900, 3, 20), "tile pipeline for the whole factorisation");
+  CHECK(gpk_get_option("potrf_tail_from") == 0, "tile pipeline from panel 0");
+  check_fit_predict(make_problem(300, 1, 5), "tile pipeline, three tiles");
+  opt("tail_rows", 0); opt("nb", 256); opt("nb_auto", 1);
   opt("nb_outer", 2048); opt("outer_from", 1 << 30); opt("outer_until", 4096); opt("nb_big", 512); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
 
   // ---- block-cyclic schedule on virtual ranks (look-ahead and plain), against the one-rank factor

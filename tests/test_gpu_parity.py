@@ -168,6 +168,42 @@ def test_potrf_block_size_invariance(gpk, nb):
     np.testing.assert_allclose(Ain @ Ain.T, A, rtol=1e-12, atol=1e-9)
 
 
+@pytest.mark.parametrize("N,opts,tail_from", [
+    (1500, {"nb": 128, "tail_rows": 1 << 30}, 0),                                   # the whole factorisation
+    (3000, {"nb_small_from": 1024, "tail_rows": 1024}, None),                       # hand-over from the panel level
+    (2100, {"nb_small_from": 2048, "tail_rows": 2048, "nb_big_until": 1024}, None), # ... from 512-wide panels
+    (640, {"nb": 128, "tail_rows": 1 << 30}, 0),                                     # five tiles: every clipped range
+    (4096, {"nb_small_from": 4096, "tail_rows": 4096}, 0),                           # BASELINE config 2's size
+])
+def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_from):
+    """potrf_tail (leaf + one-tile kernels on the chain stream, full-height panel GEMMs on a second stream, bulk on the
+    update stream) applies to every element the same rank-128 updates in the same order as the panel-level look-ahead
+    with the same 128-wide panels: the factors must agree bit for bit, and with NumPy's."""
+    rng = np.random.RandomState(N)
+    Q = rng.randn(N, N)
+    A = Q @ Q.T + N * np.eye(N)
+    out = []
+    for tail in (False, True):
+        for k, v in opts.items():
+            gpk.set_option(k, 0 if (k == "tail_rows" and not tail) else v)
+        gpk.set_option("pair_update", 0)
+        L = A.copy()
+        assert gpk.lib().gpk_potrf(_ptr(L), N) == 0, gpk.last_error()
+        tf = gpk.get_option("potrf_tail_from")
+        if tail:
+            assert tf >= 0 and (tail_from is None or tf == tail_from)
+        else:
+            assert tf == -1
+        out.append(L)
+    np.testing.assert_array_equal(out[0], out[1])
+    Lr = np.linalg.cholesky(A)
+    np.testing.assert_allclose(out[1], Lr, rtol=1e-11, atol=1e-11 * np.abs(Lr).max())
+    # not positive definite inside the tail: same LAPACK-style report
+    B = np.eye(N) * 2.0
+    B[N - 70, N - 70] = -1.0
+    assert gpk.lib().gpk_potrf(_ptr(B), N) == N - 69
+
+
 # ----------------------------------------------------------------------------- golden vectors (real reference)
 @pytest.mark.parametrize("case", golden_cases())
 def test_gpr_dropin_matches_reference_golden(gpk, case):
@@ -1065,6 +1101,8 @@ def test_gpy_compat_optimize_uses_the_device_gradient(gpk):
     {"nb_outer": 512, "outer_from": 256, "outer_until": 600, "pipe_interleave": 1},
     {"nb_outer": 1024, "outer_from": 256, "outer_until": 0, "fuse_predict": 0},
     {"nb_outer": 0},
+    {"nb": 128, "tail_rows": 1 << 30},                                              # tile pipeline for everything
+    {"nb_small_from": 1024, "tail_rows": 1024, "pipe_interleave": 1},               # ... for the last 1024 columns
 ])
 def test_option_paths_keep_parity(gpk, opts):
     """Every switch that selects another kernel or schedule must leave the posterior within the parity bar."""
