@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--dim", dest="d", type=int, default=8)
     ap.add_argument("--test-m", dest="m", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="libgpk option key=value (experiments; defaults are the product)")
     args = ap.parse_args()
 
     from gptest_amd import _lib, dist
@@ -146,6 +147,9 @@ def main():
     mean = np.zeros(M)
     var = np.zeros(M)
     _lib.check(l.gpk_set_option(b"timing", 1.0), "timing")
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.check(l.gpk_set_option(k.encode(), float(v)), "option " + k)
 
     # barrier + device sync on both sides of the timed region (gpk_bench_posterior stages the inputs,
     # runs `warmup` untimed steps, then times exactly `steps` steps with HIP events on its stream).
@@ -188,16 +192,20 @@ def main():
         kb_bytes = stage_work("kbuild")
         ach = tr_flops / (tr_ms * 1e-3) / 1e12 if tr_ms > 0 else 0.0
         # HBM traffic of that kernel per launch: PMC counters cannot be read from inside the process, so the
-        # figure comes from the committed rocprofv3 --pmc passes of this same command (scripts/pmc_traffic.sh)
+        # figure comes from the committed rocprofv3 --pmc passes of this same command (scripts/profile_round.sh)
         traffic = None
         traffic_note = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic_gemm_nt8.json")) as fh:
+            import glob
+
+            newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_gemm_nt8.json")))[-1]
+            with open(newest) as fh:
                 tj = json.load(fh)
             if world == 1 and N == 16384:
                 traffic = tj["hbm_bytes_per_launch"]
-                traffic_note = ("PMC FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE, avg over the %d trailing-update launches of one "
-                                "factorisation; algorithmic %.3g B/launch" % (tj["launches"], tj["algorithmic_bytes_per_launch"]))
+                traffic_note = ("%s: PMC FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE from two separate rocprofv3 --pmc passes of this "
+                                "command, avg over the %d trailing-update launches of one factorisation; algorithmic %.3g B/launch"
+                                % (os.path.basename(newest), tj["launches"], tj["algorithmic_bytes_per_launch"]))
         except Exception:
             pass
         flops = tr_flops / max(args.steps, 1)
@@ -233,7 +241,7 @@ def main():
             "parity": parity_detail,
             "wall_s_incl_staging": wall,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would idle in the barrier
             out["cpu_baseline"] = cpu_baseline(N, d, M)
         if parity_ok:
             print(json.dumps(out), flush=True)

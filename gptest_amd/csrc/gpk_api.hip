@@ -212,6 +212,8 @@ int gpk_set_option(const char* key, double value) {
     g_gemm_variant = (int)value;
   } else if (k == "xcd_sq") {
     G.xcd_sq = (int)value;
+  } else if (k == "xcd_sq_min_tiles") {
+    G.xcd_sq_min_tiles = (int)value;
   } else if (k == "tail_rows") {
     G.tail_rows = (int)value;
     if (G.inited && G.tail_rows > 0 && !G.s_rows) {
@@ -270,6 +272,7 @@ double gpk_get_option(const char* key) {
   if (k == "outer_from") return G.outer_from;
   if (k == "nb_outer") return G.nb_outer;
   if (k == "xcd_sq") return G.xcd_sq;
+  if (k == "xcd_sq_min_tiles") return G.xcd_sq_min_tiles;
   if (k == "pred_small_below") return G.pred_small_below;
   if (k == "small_tile_below") return G.small_tile_below;
   if (k == "pair_update") return G.pair_update;

@@ -41,7 +41,7 @@ struct Runtime {
   int tail_rows = 0;
   double last_potrf_enqueue_ms = 0.0, last_pipe_enqueue_ms = 0.0;  // host time spent queueing the last factorisation
   int timing = 0;
-  int stamps = 0;  // diagnostic: device-side progress stamps per panel (gpk_get_option("stamp_lag_*"))
+  int stamps = 0;  // diagnostic: device-side progress stamps per panel (gpk_get_option("stamp_panel_<p>" / "stamp_subst_<p>"), scripts/stamp_steps.py)
   unsigned long long* dstamps = nullptr;
   std::vector<unsigned long long> hstamps;
   int pred_small_below = 300;  // predict_update: same rule for the substitution GEMMs
@@ -52,6 +52,7 @@ struct Runtime {
   int solve_gemm_above = 8;  // gpk_solve: more right-hand sides than this go through the blocked GEMM substitutions
   int fuse_predict = 1;  // bench / compute_prediction: overlap the prediction solve with the factorisation tail
   int xcd_sq = 1;              // XCD-aware 8x8-tile square order in the big GEMMs
+  int xcd_sq_min_tiles = 8192; // ... for launches with at least this many 128x128 tiles in the bounding rectangle
   int ncu = 256;         // CUs available to the GEMM streams
   int small_tile_rows = 4096;  // GEMMs with n == 128 use the 64x64 tile below this many rows... (see potrf)
   // comm

@@ -239,7 +239,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = (Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16)[c_off];
+        for (int r = 0; r < 4; ++r)  // read once per launch: non-temporal, so that the C stream does not evict panel lines from L2
+          acc[i][j][r] = __builtin_nontemporal_load((Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16) + c_off);
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
