@@ -148,9 +148,9 @@ def init(device=None):
 def shutdown(watchdog_s=None):
     """Release streams, events and pooled HBM (gpk_shutdown).  ``watchdog_s``: run the release on a helper thread;
     if it has not returned in time the process is ended with exit status 3 -- a stuck teardown is a failure and must
-    be visible to whoever launched the script, even though its results are already printed.  (Round 1 saw
-    hipStreamDestroy hang on a CU-masked stream for one destroy order; gpk_shutdown uses the order that does not,
-    scripts/shutdown_probe.py replays both.)"""
+    be visible to whoever launched the script, even though its results are already printed.  (What used to hang is
+    characterised in gpk_shutdown: a destroyed CU-masked stream makes the HIP runtime's own exit hang, so that stream
+    is left to process teardown unless a profiler is attached; scripts/shutdown_probe.py reproduces the matrix.)"""
     global _inited
     if _lib is None or not _inited:
         _inited = False

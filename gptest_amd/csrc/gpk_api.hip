@@ -16,6 +16,10 @@ int gpk_device_count(void) {
   return n;
 }
 
+// the CU-masked update stream of an earlier gpk_init / gpk_shutdown cycle (see gpk_shutdown)
+static hipStream_t g_parked_main = nullptr;
+static int g_parked_device = -1, g_parked_reserved = 0;
+
 int gpk_init(int device) {
   if (G.inited) {
     if (device == G.device) return 0;
@@ -59,7 +63,13 @@ int gpk_init(int device) {
         m_all[r / 32] &= ~(1u << (r % 32));
       }
     G.ncu_reserved = 8 * per_xcd;
-    hipError_t e1 = hipExtStreamCreateWithCUMask(&G.s_main, words, m_all.data());
+    hipError_t e1 = hipSuccess;
+    if (g_parked_main && g_parked_device == device && g_parked_reserved == G.ncu_reserved) {
+      G.s_main = g_parked_main;
+      g_parked_main = nullptr;
+    } else {
+      e1 = hipExtStreamCreateWithCUMask(&G.s_main, words, m_all.data());
+    }
     // s_panel (the latency-critical panel chain): high PRIORITY instead of a mask -- the two cannot be combined
     // through HIP.  Its skinny GEMMs may also use the reserved CU; a leaf only ever follows them in stream
     // order, so the CU is empty again when the leaf arrives.  GPK_PANEL_PRIO=0 restores the masked stream.
@@ -111,19 +121,15 @@ int gpk_init(int device) {
   G.ncu = masked ? ncu - G.ncu_reserved : ncu;
   G.device = device;
   {
-    // Touch every stream once.  The runtime builds a stream's hardware queue lazily; destroying a CU-masked
-    // stream whose queue was never built hangs in hipStreamDestroy (seen at interpreter exit of a process that
-    // only ever used the update stream), and the first real launch on each stream no longer pays for the build.
-    const char* env_nt = getenv("GPK_NO_TOUCH");  // diagnostic (scripts/shutdown_probe.py)
-    if (!(env_nt && env_nt[0] == '1')) {
-      unsigned long long* dtouch = nullptr;
-      GPK_HIP(hipMalloc((void**)&dtouch, 64));
-      hipStream_t all[4] = {G.s_main, G.s_panel, nullptr, G.s_pred};
-      for (int i = 0; i < 4; ++i)
-        if (all[i]) GPK_TRY(launch_stamp(dtouch + i, all[i]));
-      GPK_HIP(hipDeviceSynchronize());
-      (void)hipFree(dtouch);
-    }
+    // One launch per stream: the runtime builds a stream's hardware queue lazily, so the first real launch on each
+    // stream does not pay for it.  (Not a teardown measure: see gpk_shutdown for what is.)
+    unsigned long long* dtouch = nullptr;
+    GPK_HIP(hipMalloc((void**)&dtouch, 64));
+    hipStream_t all[3] = {G.s_main, G.s_panel, G.s_pred};
+    for (int i = 0; i < 3; ++i)
+      if (all[i]) GPK_TRY(launch_stamp(dtouch + i, all[i]));
+    GPK_HIP(hipDeviceSynchronize());
+    (void)hipFree(dtouch);
   }
   G.inited = true;
   return 0;
@@ -151,16 +157,25 @@ void gpk_shutdown(void) {
   timers_reset();
   for (hipEvent_t e : G.ev_free) (void)hipEventDestroy(e);
   G.ev_free.clear();
-  // Destroy order: substitution stream, update stream (CU-masked), optional leaf stream (CU-masked), panel chain.
-  // Round 1 saw hipStreamDestroy of the masked leaf stream hang when the masked update stream and then the
-  // substitution stream had been destroyed before it; GPK_SHUTDOWN_ORDER=old replays that order for
-  // scripts/shutdown_probe.py (diagnosis only).
-  const char* env_order = getenv("GPK_SHUTDOWN_ORDER");
-  const bool old_order = env_order && !strcmp(env_order, "old");
-  if (old_order) SD_STEP("destroy s_main", if (G.s_main) (void)hipStreamDestroy(G.s_main));
+  // The CU-masked update stream is NOT destroyed: measured on this pool (scripts/shutdown_probe.py,
+  // profiles/r02_shutdown_probe.txt), hipStreamDestroy of a hipExtStreamCreateWithCUMask stream returns, but the
+  // process then hangs in the HIP runtime's own teardown at exit (3 of 3 after a process that had mostly used that
+  // stream; any destroy order, with or without the warm-up launches of gpk_init), while a process that leaves the
+  // stream to process teardown exits cleanly (4 of 4).  The one exception is a process running under rocprofv3, where
+  // it is the other way round (a live masked stream at exit: SIGSEGV in the tool's __cxa_finalize; destroyed: clean) --
+  // so the stream is destroyed only there (ROCP_TOOL_LIBRARIES set) or on request (GPK_DESTROY_MASKED=1).  A kept
+  // stream is parked and reused by the next gpk_init on the same device.
+  const char* env_dm = getenv("GPK_DESTROY_MASKED");
+  const bool destroy_masked = !G.cu_reserved || (env_dm ? env_dm[0] == '1' : getenv("ROCP_TOOL_LIBRARIES") != nullptr);
   SD_STEP("destroy s_pred", if (G.s_pred && G.s_pred != G.s_panel) (void)hipStreamDestroy(G.s_pred));
   G.s_pred = nullptr;
-  if (!old_order) SD_STEP("destroy s_main", if (G.s_main) (void)hipStreamDestroy(G.s_main));
+  if (destroy_masked) {
+    SD_STEP("destroy s_main", if (G.s_main) (void)hipStreamDestroy(G.s_main));
+  } else {
+    g_parked_main = G.s_main;
+    g_parked_device = G.device;
+    g_parked_reserved = G.ncu_reserved;
+  }
   SD_STEP("destroy s_rows", if (G.s_rows) (void)hipStreamDestroy(G.s_rows));
   SD_STEP("destroy s_panel", if (G.s_panel) (void)hipStreamDestroy(G.s_panel));
   SD_STEP("destroy events", {

@@ -14,10 +14,38 @@
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-template <int D>  // D = 0: runtime dimension (column points re-read from LDS)
+// 2^t for t <= ~10 (the SE kernel: t = log2(sf2) - r^2 log2(e)/2), ~1 ulp: round to the nearest integer, degree-13
+// Taylor polynomial of 2^f on |f| <= 1/2 (truncation 4e-18 relative), exponent added with v_ldexp (gradual underflow
+// to 0 for very negative t comes for free).  ~18 VALU operations against ~30 of the library exp() with its range and
+// special-value handling: with d = 8 the builder is VALU-bound on exactly that difference.
+__device__ __forceinline__ double exp2_neg(double t) {
+  t = (t < -1100.0) ? -1100.0 : t;  // not fmax: a NaN input must stay NaN (non-finite points have to fail the factorisation)
+  const double n = rint(t);
+  const double f = t - n;
+  double p = 1.3691488853904124e-12;   // ln2^13/13!
+  p = fma(p, f, 2.5678435993488196e-11);
+  p = fma(p, f, 4.44553827187081e-10);
+  p = fma(p, f, 7.054911620801121e-09);
+  p = fma(p, f, 1.0178086009239696e-07);
+  p = fma(p, f, 1.3215486790144305e-06);
+  p = fma(p, f, 1.5252733804059838e-05);
+  p = fma(p, f, 0.00015403530393381606);
+  p = fma(p, f, 0.0013333558146428441);
+  p = fma(p, f, 0.009618129107628477);
+  p = fma(p, f, 0.055504108664821576);
+  p = fma(p, f, 0.2402265069591007);
+  p = fma(p, f, 0.6931471805599453);
+  p = fma(p, f, 1.0);
+  return ldexp(p, (int)n);
+}
+
+// MODE 0: sf2 exp(-r^2/2) (+ diag_add on the diagonal of a same-set build), 1: plain r^2, 2: stores only (timing).
+// In mode 0 the points are pre-scaled by sqrt(log2(e)/2)/ell so that the accumulated squared distance IS the (negated)
+// base-2 exponent, and log2(sf2) is folded into it: one add + exp2_neg per element instead of two multiplies + exp().
+template <int D, int MODE>  // D = 0: runtime dimension (column points re-read from LDS)
 __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict__ R, int nr,
                                                        const double* __restrict__ Cc, int nc, SEParams p,
-                                                       int same_set, int mode, int lower_only,
+                                                       int same_set, int lower_only,
                                                        double* __restrict__ out, long ld, int col_g0) {
   constexpr int DMAX = (D == 0) ? 32 : D;
   __shared__ double rs[128 * DMAX];
@@ -28,14 +56,16 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
   if (lower_only && col_g0 + tc * 128 > tr * 128 + 127) return;
   const int r0 = tr * 128, c0 = tc * 128;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const double pre = (MODE == 0) ? 0.8493218002880191 : 1.0;  // sqrt(log2(e) / 2)
+  const double lsf = (MODE == 0) ? log2(p.sf2) : 0.0;
 
   for (int e = tid; e < 128 * d; e += 256) {
     const int i = e / d, k = e - i * d;
     const int gi = r0 + i;
-    rs[e] = (gi < nr) ? R[(long)gi * d + k] / p.ell[k] : 0.0;
+    rs[e] = (gi < nr) ? R[(long)gi * d + k] / p.ell[k] * pre : 0.0;
     if (D == 0) {
       const int gc = c0 + i;
-      cs[e] = (gc < nc) ? Cc[(long)gc * d + k] / p.ell[k] : 0.0;
+      cs[e] = (gc < nc) ? Cc[(long)gc * d + k] / p.ell[k] * pre : 0.0;
     }
   }
   const int ca = c0 + 2 * lane, cb = ca + 1;
@@ -43,11 +73,14 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
   if (D != 0) {
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      za[k] = (ca < nc) ? Cc[(long)ca * D + k] / p.ell[k] : 0.0;
-      zb[k] = (cb < nc) ? Cc[(long)cb * D + k] / p.ell[k] : 0.0;
+      za[k] = (ca < nc) ? Cc[(long)ca * D + k] / p.ell[k] * pre : 0.0;
+      zb[k] = (cb < nc) ? Cc[(long)cb * D + k] / p.ell[k] * pre : 0.0;
     }
   }
   __syncthreads();
+  // interior tiles (the vast majority) need neither the padding rule nor the diagonal term: uniform per workgroup
+  const bool edge = (r0 + 128 > nr) || (c0 + 128 > nc);
+  const bool diag = same_set && (col_g0 + c0 < r0 + 128) && (r0 < col_g0 + c0 + 128);
 
   for (int rr = 0; rr < 32; ++rr) {
     const int i = w * 32 + rr;
@@ -58,52 +91,50 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
       for (int k = 0; k < D; ++k) {
         const double x = rs[i * D + k];
         const double e0 = x - za[k], e1 = x - zb[k];
-        s0 += e0 * e0;
-        s1 += e1 * e1;
+        s0 = fma(e0, e0, s0);
+        s1 = fma(e1, e1, s1);
       }
     } else {
       for (int k = 0; k < d; ++k) {
         const double x = rs[i * d + k];
         const double e0 = x - cs[(2 * lane) * d + k], e1 = x - cs[(2 * lane + 1) * d + k];
-        s0 += e0 * e0;
-        s1 += e1 * e1;
+        s0 = fma(e0, e0, s0);
+        s1 = fma(e1, e1, s1);
       }
     }
     double v0, v1;
-    if (mode == 1) {
+    if (MODE == 1) {
       v0 = s0;
       v1 = s1;
-    } else if (mode == 2) {  // timing experiment: stores only
+    } else if (MODE == 2) {  // timing experiment: stores only
       v0 = 1.0;
       v1 = 2.0;
     } else {
-      v0 = p.sf2 * exp(-0.5 * s0);
-      v1 = p.sf2 * exp(-0.5 * s1);
-      if (same_set) {
+      v0 = exp2_neg(lsf - s0);
+      v1 = exp2_neg(lsf - s1);
+      if (diag) {
         if (gi == col_g0 + ca) v0 += p.diag_add;
         if (gi == col_g0 + cb) v1 += p.diag_add;
       }
     }
-    const bool rok = gi < nr;
-    if (!(rok && ca < nc)) v0 = (same_set && gi == col_g0 + ca) ? 1.0 : 0.0;  // padding: identity / zero
-    if (!(rok && cb < nc)) v1 = (same_set && gi == col_g0 + cb) ? 1.0 : 0.0;
+    if (edge) {
+      const bool rok = gi < nr;
+      if (!(rok && ca < nc)) v0 = (same_set && gi == col_g0 + ca) ? 1.0 : 0.0;  // padding: identity / zero
+      if (!(rok && cb < nc)) v1 = (same_set && gi == col_g0 + cb) ? 1.0 : 0.0;
+    }
     d2 o = {v0, v1};
     *reinterpret_cast<d2*>(out + (long)gi * ld + ca) = o;
   }
 }
 
-int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p,
-                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0) {
-  if (nr_pad % 128 || nc_pad % 128 || (ld & 1) || ((uintptr_t)out & 15))
-    return gpk_set_err(-1, "se_build: padded shape %dx%d ld %ld must be tile aligned", nr_pad, nc_pad, ld);
-  if (p.d < 1 || p.d > 32) return gpk_set_err(-1, "se_build: input dimension d=%d outside 1..32", p.d);
-  dim3 grid(nc_pad / 128, nr_pad / 128), block(256);
-  const int lo = (int)lower_only;
-#define GPK_SE_CASE(DD)                                                                                            \
-  case DD:                                                                                                         \
-    hipLaunchKernelGGL(se_build_kernel<DD>, grid, block, 0, s, R, nr, Cc, nc, p, same_set, mode, lo, out, ld, col_g0); \
+template <int MODE>
+static void se_build_dispatch(int dd, dim3 grid, dim3 block, hipStream_t s, const double* R, int nr, const double* Cc, int nc,
+                              const SEParams& p, int same_set, int lo, double* out, long ld, int col_g0) {
+#define GPK_SE_CASE(DD)                                                                                                 \
+  case DD:                                                                                                              \
+    hipLaunchKernelGGL((se_build_kernel<DD, MODE>), grid, block, 0, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0); \
     break;
-  switch (p.d) {
+  switch (dd) {
     GPK_SE_CASE(1)
     GPK_SE_CASE(2)
     GPK_SE_CASE(3)
@@ -113,9 +144,21 @@ int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int n
     GPK_SE_CASE(7)
     GPK_SE_CASE(8)
     default:
-      hipLaunchKernelGGL(se_build_kernel<0>, grid, block, 0, s, R, nr, Cc, nc, p, same_set, mode, lo, out, ld, col_g0);
+      hipLaunchKernelGGL((se_build_kernel<0, MODE>), grid, block, 0, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0);
   }
 #undef GPK_SE_CASE
+}
+
+int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p,
+                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0) {
+  if (nr_pad % 128 || nc_pad % 128 || (ld & 1) || ((uintptr_t)out & 15))
+    return gpk_set_err(-1, "se_build: padded shape %dx%d ld %ld must be tile aligned", nr_pad, nc_pad, ld);
+  if (p.d < 1 || p.d > 32) return gpk_set_err(-1, "se_build: input dimension d=%d outside 1..32", p.d);
+  dim3 grid(nc_pad / 128, nr_pad / 128), block(256);
+  const int lo = (int)lower_only;
+  if (mode == 0) se_build_dispatch<0>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0);
+  else if (mode == 1) se_build_dispatch<1>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0);
+  else se_build_dispatch<2>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0);
   GPK_HIP(hipGetLastError());
   return 0;
 }
