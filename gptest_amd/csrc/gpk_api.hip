@@ -318,23 +318,17 @@ static int se_build_host(const double* Rh, int nr, const double* Ch, int nc, int
   if (nr < 1 || nc < 1) return gpk_set_err(-1, "empty input (%d x %d)", nr, nc);
   hipStream_t s = G.s_main;
   const int nrp = round_up(nr, 128), ncp = round_up(nc, 128);
+  Scratch sc;  // returned to the pool on every path
   double *dR = nullptr, *dC = nullptr, *dO = nullptr;
-  GPK_TRY(dev_alloc_t(&dR, (size_t)nr * d));
-  if (!same) GPK_TRY(dev_alloc_t(&dC, (size_t)nc * d));
-  GPK_TRY(dev_alloc_t(&dO, (size_t)nrp * ncp));
-  int rc = 0;
-  do {
-    if (hipMemcpyAsync(dR, Rh, (size_t)nr * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    if (!same && hipMemcpyAsync(dC, Ch, (size_t)nc * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    rc = launch_se_build(dR, nr, nrp, same ? dR : dC, nc, ncp, se, same, mode, dO, ncp, 0, s);
-    if (rc) break;
-    if (hipMemcpy2DAsync(out_h, (size_t)nc * 8, dO, (size_t)ncp * 8, (size_t)nc * 8, nr, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "stream sync failed: %s", hipGetErrorString(hipGetLastError())); break; }
-  } while (0);
-  dev_free(dR, (size_t)nr * d * 8);
-  if (dC) dev_free(dC, (size_t)nc * d * 8);
-  dev_free(dO, (size_t)nrp * ncp * 8);
-  return rc;
+  GPK_TRY(sc.get(&dR, (size_t)nr * d));
+  if (!same) GPK_TRY(sc.get(&dC, (size_t)nc * d));
+  GPK_TRY(sc.get(&dO, (size_t)nrp * ncp));
+  GPK_HIP(hipMemcpyAsync(dR, Rh, (size_t)nr * d * 8, hipMemcpyHostToDevice, s));
+  if (!same) GPK_HIP(hipMemcpyAsync(dC, Ch, (size_t)nc * d * 8, hipMemcpyHostToDevice, s));
+  GPK_TRY(launch_se_build(dR, nr, nrp, same ? dR : dC, nc, ncp, se, same, mode, dO, ncp, 0, s));
+  GPK_HIP(hipMemcpy2DAsync(out_h, (size_t)nc * 8, dO, (size_t)ncp * 8, (size_t)nc * 8, nr, hipMemcpyDeviceToHost, s));
+  GPK_HIP(hipStreamSynchronize(s));
+  return 0;
 }
 
 int gpk_sqdist(const double* A, int n, const double* B, int m, int d, double* out) {
@@ -568,50 +562,44 @@ int gpk_kmatvec(gpk_model* m, const double* B, int nrhs, double* out) {
   GPK_TRY(rt_require());
   if (!m || !B || !out) return gpk_set_err(-1, "gpk_kmatvec: null pointer");
   if (!m->dKcopy) return gpk_set_err(-1, "gpk_kmatvec: model was fitted without the keep-K flag");
+  if (nrhs < 1) return gpk_set_err(-1, "gpk_kmatvec: nrhs=%d must be >= 1", nrhs);
   hipStream_t s = G.s_main;
   const int N = m->N, np_ = m->Npad;
-  double *dv = nullptr, *dr = nullptr;
-  GPK_TRY(dev_alloc_t(&dv, (size_t)np_));
-  GPK_TRY(dev_alloc_t(&dr, (size_t)np_));
-  std::vector<double> col(np_, 0.0);
-  int rc = 0;
-  for (int j = 0; j < nrhs && !rc; ++j) {
-    for (int i = 0; i < N; ++i) col[i] = B[(size_t)i * nrhs + j];
-    for (int i = N; i < np_; ++i) col[i] = 0.0;
-    if (hipMemcpyAsync(dv, col.data(), (size_t)np_ * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    rc = launch_gemv(m->dKcopy, np_, np_, np_, dv, dr, 1.0, 0.0, s);
-    if (rc) break;
-    if (hipMemcpyAsync(col.data(), dr, (size_t)N * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "kmatvec: %s", hipGetErrorString(hipGetLastError())); break; }
-    for (int i = 0; i < N; ++i) out[(size_t)i * nrhs + j] = col[i];
-  }
-  dev_free(dv, (size_t)np_ * 8);
-  dev_free(dr, (size_t)np_ * 8);
-  return rc;
+  const size_t szB = (size_t)N * nrhs, szR = (size_t)nrhs * np_;
+  Scratch sc;
+  double *dB = nullptr, *dV = nullptr, *dW = nullptr;
+  GPK_TRY(sc.get(&dB, szB));
+  GPK_TRY(sc.get(&dV, szR));
+  GPK_TRY(sc.get(&dW, szR));
+  GPK_HIP(hipMemcpyAsync(dB, B, szB * 8, hipMemcpyHostToDevice, s));
+  GPK_HIP(hipMemsetAsync(dV, 0, szR * 8, s));
+  GPK_TRY(launch_transpose(dB, nrhs, N, nrhs, dV, np_, s));  // one zero-padded vector per row
+  for (int j = 0; j < nrhs; ++j)
+    GPK_TRY(launch_gemv(m->dKcopy, np_, np_, np_, dV + (size_t)j * np_, dW + (size_t)j * np_, 1.0, 0.0, s));
+  GPK_TRY(launch_transpose(dW, np_, nrhs, N, dB, nrhs, s));
+  GPK_HIP(hipMemcpyAsync(out, dB, szB * 8, hipMemcpyDeviceToHost, s));
+  GPK_HIP(hipStreamSynchronize(s));
+  return 0;
 }
 
 int gpk_kgather(gpk_model* m, const long long* idx, int nidx, double* out) {
   GPK_TRY(rt_require());
   if (!m || !idx || !out) return gpk_set_err(-1, "gpk_kgather: null pointer");
   if (!m->dKcopy) return gpk_set_err(-1, "gpk_kgather: model was fitted without the keep-K flag");
+  if (nidx < 1) return gpk_set_err(-1, "gpk_kgather: nidx=%d must be >= 1", nidx);
   for (int i = 0; i < nidx; ++i)
     if (idx[i] < 0 || idx[i] >= m->N) return gpk_set_err(-1, "gpk_kgather: index %lld outside 0..%d", idx[i], m->N - 1);
   hipStream_t s = G.s_main;
+  Scratch sc;
   long long* didx = nullptr;
   double* dout = nullptr;
-  GPK_TRY(dev_alloc_t(&didx, (size_t)nidx));
-  GPK_TRY(dev_alloc_t(&dout, (size_t)nidx * nidx));
-  int rc = 0;
-  do {
-    if (hipMemcpyAsync(didx, idx, (size_t)nidx * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    rc = launch_gather2d(m->dKcopy, m->Npad, didx, nidx, dout, s);
-    if (rc) break;
-    if (hipMemcpyAsync(out, dout, (size_t)nidx * nidx * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "kgather: %s", hipGetErrorString(hipGetLastError())); break; }
-  } while (0);
-  dev_free(didx, (size_t)nidx * 8);
-  dev_free(dout, (size_t)nidx * nidx * 8);
-  return rc;
+  GPK_TRY(sc.get(&didx, (size_t)nidx));
+  GPK_TRY(sc.get(&dout, (size_t)nidx * nidx));
+  GPK_HIP(hipMemcpyAsync(didx, idx, (size_t)nidx * 8, hipMemcpyHostToDevice, s));
+  GPK_TRY(launch_gather2d(m->dKcopy, m->Npad, didx, nidx, dout, s));
+  GPK_HIP(hipMemcpyAsync(out, dout, (size_t)nidx * nidx * 8, hipMemcpyDeviceToHost, s));
+  GPK_HIP(hipStreamSynchronize(s));
+  return 0;
 }
 
 int gpk_nlml_grad(gpk_model* m, double* grad_out) {
@@ -823,46 +811,35 @@ int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
 
 int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile) {
   GPK_TRY(rt_require());
+  if (!A || !B || !C || m < 1 || n < 1 || k < 1) return gpk_set_err(-1, "gpk_test_gemm_nt: bad arguments");
   hipStream_t s = G.s_main;
-  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
-  GPK_TRY(dev_alloc_t(&dA, (size_t)m * k));
-  GPK_TRY(dev_alloc_t(&dB, (size_t)n * k));
-  GPK_TRY(dev_alloc_t(&dC, (size_t)m * n));
-  int rc = 0;
-  do {
-    if (hipMemcpyAsync(dA, A, (size_t)m * k * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    if (hipMemcpyAsync(dB, B, (size_t)n * k * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    if (hipMemcpyAsync(dC, C, (size_t)m * n * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    GemmNT g{};
-    g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
-    g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
-    g.xcd_sq = (G.xcd_sq == 2 && tile == 128) ? 1 : 0;  // option xcd_sq = 2: force the XCD-aware tile order (tests)
-    double *dA2 = nullptr, *dB2 = nullptr;
-    const int k1 = G.test_gemm_k1;
-    if (k1 > 0 && k1 < k) {
-      // same product with the K range split over two separately stored operands (the paired trailing update)
-      // second segment stored separately but with the same leading dimension k (columns [0, k2) used)
-      const int k2 = k - k1;
-      if (dev_alloc_t(&dA2, (size_t)m * k) || dev_alloc_t(&dB2, (size_t)n * k)) { rc = -2; break; }
-      if (hipMemcpy2DAsync(dA2, (size_t)k * 8, dA + k1, (size_t)k * 8, (size_t)k2 * 8, m, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-          hipMemcpy2DAsync(dB2, (size_t)k * 8, dB + k1, (size_t)k * 8, (size_t)k2 * 8, n, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-        rc = gpk_set_err(-2, "segment copy failed");
-        break;
-      }
-      g.A2 = dA2; g.lda2 = k; g.B2 = dB2; g.ldb2 = k; g.k1 = k1;
-    }
-    rc = launch_gemm_nt(g, tile == 128, s);
-    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = gpk_set_err(-2, "test_gemm: %s", hipGetErrorString(hipGetLastError()));
-    if (dA2) dev_free(dA2, (size_t)m * k * 8);
-    if (dB2) dev_free(dB2, (size_t)n * k * 8);
-    if (rc) break;
-    if (hipMemcpyAsync(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "test_gemm: %s", hipGetErrorString(hipGetLastError())); break; }
-  } while (0);
-  dev_free(dA, (size_t)m * k * 8);
-  dev_free(dB, (size_t)n * k * 8);
-  dev_free(dC, (size_t)m * n * 8);
-  return rc;
+  Scratch sc;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr, *dA2 = nullptr, *dB2 = nullptr;
+  GPK_TRY(sc.get(&dA, (size_t)m * k));
+  GPK_TRY(sc.get(&dB, (size_t)n * k));
+  GPK_TRY(sc.get(&dC, (size_t)m * n));
+  GPK_HIP(hipMemcpyAsync(dA, A, (size_t)m * k * 8, hipMemcpyHostToDevice, s));
+  GPK_HIP(hipMemcpyAsync(dB, B, (size_t)n * k * 8, hipMemcpyHostToDevice, s));
+  GPK_HIP(hipMemcpyAsync(dC, C, (size_t)m * n * 8, hipMemcpyHostToDevice, s));
+  GemmNT g{};
+  g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
+  g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
+  g.xcd_sq = (G.xcd_sq == 2 && tile == 128) ? 1 : 0;  // option xcd_sq = 2: force the XCD-aware tile order (tests)
+  const int k1 = G.test_gemm_k1;
+  if (k1 > 0 && k1 < k) {
+    // same product with the K range split over two separately stored operands (the paired trailing update);
+    // second segment stored separately but with the same leading dimension k (columns [0, k2) used)
+    const int k2 = k - k1;
+    GPK_TRY(sc.get(&dA2, (size_t)m * k));
+    GPK_TRY(sc.get(&dB2, (size_t)n * k));
+    GPK_HIP(hipMemcpy2DAsync(dA2, (size_t)k * 8, dA + k1, (size_t)k * 8, (size_t)k2 * 8, m, hipMemcpyDeviceToDevice, s));
+    GPK_HIP(hipMemcpy2DAsync(dB2, (size_t)k * 8, dB + k1, (size_t)k * 8, (size_t)k2 * 8, n, hipMemcpyDeviceToDevice, s));
+    g.A2 = dA2; g.lda2 = k; g.B2 = dB2; g.ldb2 = k; g.k1 = k1;
+  }
+  GPK_TRY(launch_gemm_nt(g, tile == 128, s));
+  GPK_HIP(hipMemcpyAsync(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost, s));
+  GPK_HIP(hipStreamSynchronize(s));
+  return 0;
 }
 
 int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out) {

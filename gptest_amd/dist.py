@@ -45,49 +45,77 @@ def torch_bootstrap(payload):
     return bytes(t.tolist())
 
 
+_MAGIC = b"GPKUID1\n"
+_PORT_TRIES = 8
+
+
+def _bootstrap_ports():
+    base = (int(os.environ.get("MASTER_PORT", "29500")) + 7919) % 65536
+    if base < 1024:
+        base += 20000
+    return [1024 + (base - 1024 + 101 * i) % (65536 - 1024) for i in range(_PORT_TRIES)]
+
+
 def socket_bootstrap(payload, rank=None, world=None, timeout=120.0):
     """Broadcast rank 0's bytes over plain TCP (no torch in the product path).  Rank 0 listens next to the
-    launcher's rendezvous port (MASTER_PORT + 7919), the other ranks connect with retries."""
+    launcher's rendezvous port (MASTER_PORT + 7919, or the next of a fixed sequence of ports if that one is taken),
+    the other ranks connect with retries; every message starts with a magic tag so that a foreign listener on one of
+    the candidate ports is recognised and skipped."""
     import socket
     import time
 
     if rank is None or world is None:
         rank, _, world = env_rank()
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    port = (int(os.environ.get("MASTER_PORT", "29500")) + 7919) % 65536
-    if port < 1024:
-        port += 20000
+    ports = _bootstrap_ports()
     if rank == 0:
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((host, port))
+        srv = None
+        for port in ports:
+            try:
+                cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                cand.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                cand.bind((host, port))
+                srv = cand
+                break
+            except OSError:
+                cand.close()
+        if srv is None:
+            raise OSError("no free bootstrap port among %r on %s" % (ports, host))
         srv.listen(world)
         srv.settimeout(timeout)
         try:
             for _ in range(world - 1):
                 c, _addr = srv.accept()
-                c.sendall(payload)
+                c.sendall(_MAGIC + payload)
                 c.close()
         finally:
             srv.close()
         return payload
     deadline = time.time() + timeout
+    want = len(_MAGIC) + UID_BYTES
     while True:
-        try:
-            c = socket.create_connection((host, port), timeout=5.0)
-            break
-        except OSError:
-            if time.time() > deadline:
-                raise
-            time.sleep(0.05)
-    buf = b""
-    while len(buf) < UID_BYTES:
-        chunk = c.recv(UID_BYTES - len(buf))
-        if not chunk:
-            break
-        buf += chunk
-    c.close()
-    return buf
+        for port in ports:
+            try:
+                c = socket.create_connection((host, port), timeout=2.0)
+            except OSError:
+                continue
+            try:
+                c.settimeout(10.0)
+                buf = b""
+                while len(buf) < want:
+                    chunk = c.recv(want - len(buf))
+                    if not chunk:
+                        break
+                    buf += chunk
+            except OSError:
+                buf = b""
+            finally:
+                c.close()
+            if len(buf) == want and buf.startswith(_MAGIC):
+                return buf[len(_MAGIC):]
+        if time.time() > deadline:
+            raise TimeoutError("rank %d: no bootstrap server answered on %s ports %r" % (rank, host, ports))
+        time.sleep(0.05)
 
 
 def init_comm(rank, world, bootstrap=socket_bootstrap, device=None):

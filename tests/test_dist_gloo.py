@@ -108,3 +108,60 @@ def test_socket_bootstrap_two_processes(tmp_path):
     outs = [p.communicate(timeout=120) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, o + e
+
+
+def test_socket_bootstrap_skips_a_foreign_listener(tmp_path):
+    """The first candidate port is taken by some other service (it answers, but not with the magic tag): rank 0 moves
+    to the next port of the fixed sequence and the other ranks find it there.  Three ranks."""
+    import threading
+
+    probe = socket.socket()
+    probe.bind(("127.0.0.1", 0))
+    port = probe.getsockname()[1]
+    probe.close()
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        ports = dist._bootstrap_ports()
+    finally:
+        del os.environ["MASTER_PORT"]
+    foreign = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    foreign.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        foreign.bind(("127.0.0.1", ports[0]))
+    except OSError:
+        pytest.skip("candidate port already in use on this machine")
+    foreign.listen(8)
+    foreign.settimeout(0.2)
+    stop = []
+
+    def serve():
+        while not stop:
+            try:
+                c, _ = foreign.accept()
+            except OSError:
+                continue
+            c.sendall(b"HTTP/1.1 400 Bad Request\r\n\r\n")
+            c.close()
+
+    th = threading.Thread(target=serve, daemon=True)
+    th.start()
+    code = textwrap.dedent(
+        """
+        import os, sys
+        sys.path.insert(0, %r)
+        from gptest_amd import dist
+        rank = int(os.environ["RANK"])
+        got = dist.socket_bootstrap(bytes(range(128)) if rank == 0 else None, timeout=60.0)
+        assert got == bytes(range(128))
+        sys.stdout.write("ok " + str(rank) + chr(10))
+        """
+    ) % ROOT
+    procs = []
+    for r in (0, 1, 2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    stop.append(1)
+    foreign.close()
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, o + e
