@@ -86,15 +86,18 @@ int gpk_init(int device) {
     // only exists while option tail_rows > 0: an idle fourth stream costs 4 % at N = 4096 (3.18 -> 3.32 ms, A/B on one box).
     hipError_t e3 = e2;  // (s_rows is created when the tile pipeline is switched on: option tail_rows)
     if (e3 == hipSuccess) {
-      // s_pred (forward substitutions pipelined behind the panels): priority instead of a mask, otherwise its
-      // kernels queue behind thousands of trailing-update workgroups and the whole backlog (2.7 ms measured)
-      // is left over when the factorisation ends.  GPK_PRED_PRIO=0 restores the masked stream.
+      // s_pred (forward substitutions pipelined behind the panels): an unmasked stream of its own rather than a
+      // second masked one (round 1: masked, its kernels queued behind thousands of trailing-update workgroups and a
+      // 2.7 ms backlog was left over when the factorisation ended).  High priority.  Round 2 re-measured LOW priority
+      // (below the update stream, whose rest-updates feed the panel chain): N = 16384 28.0-28.1 posteriors/s and
+      // 42.6-43.1 TFLOP/s on the trailing update against 28.0 and 41.5 (A/B/A/B on one box), but N = 4096, where the
+      // substitutions ARE a critical chain, becomes bimodal (3.15 / 3.28-3.33 ms against 3.14-3.15): high stays.
       // The y substitution shares this stream.  Stream COUNT matters on this part: with the y chain on a stream
       // of its own the posterior rate at N = 16384 was 23.6 (high priority) / 24.8 (normal) against 25.6 here,
       // one further idle high-priority stream took it to 19-20, and moving the substitutions onto the panel
       // chain's stream to 22.4.  Dropping the leaf stream as well (see above) leaves three: update, panel chain,
       // substitutions.
-      const char* env_qp = getenv("GPK_PRED_PRIO");
+      const char* env_qp = getenv("GPK_PRED_PRIO");  // 0: CU mask instead, 2: middle, 3: low, default: HIGH priority
       if (env_qp && env_qp[0] == '0') e3 = hipExtStreamCreateWithCUMask(&G.s_pred, words, m_all.data());
       else if (env_qp && env_qp[0] == '2') e3 = hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, (plo + phi) / 2);
       else if (env_qp && env_qp[0] == '3') e3 = hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, plo);
