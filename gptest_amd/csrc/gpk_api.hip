@@ -180,6 +180,8 @@ void gpk_shutdown(void) {
     g_parked_reserved = G.ncu_reserved;
   }
   SD_STEP("destroy s_rows", if (G.s_rows) (void)hipStreamDestroy(G.s_rows));
+  SD_STEP("destroy s_comm", if (G.s_comm) (void)hipStreamDestroy(G.s_comm));
+  G.s_comm = nullptr;
   SD_STEP("destroy s_panel", if (G.s_panel) (void)hipStreamDestroy(G.s_panel));
   SD_STEP("destroy events", {
     for (hipEvent_t e : G.ev_dep_free) (void)hipEventDestroy(e);
@@ -225,6 +227,9 @@ int gpk_set_option(const char* key, double value) {
     G.nb_outer = (int)value;
   } else if (k == "lookahead") {
     G.lookahead = (int)value;
+  } else if (k == "dist_group") {
+    if ((int)value < 1 || (int)value > 64) return gpk_set_err(-1, "dist_group must be in 1..64");
+    G.dist_group = (int)value;
   } else if (k == "gemm_variant") {
     extern int g_gemm_variant;
     g_gemm_variant = (int)value;
@@ -274,6 +279,7 @@ double gpk_get_option(const char* key) {
   std::string k(key ? key : "");
   if (k == "nb") return G.nb;
   if (k == "lookahead") return G.lookahead;
+  if (k == "dist_group") return G.dist_group;
   if (k == "timing") return G.timing;
   if (k == "pool_bytes") return (double)G.pool_bytes;
   if (k == "potrf_enqueue_ms") return G.last_potrf_enqueue_ms;
@@ -742,11 +748,11 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
 }  // extern "C"
 
 // ---------------------------------------------------------------- kernel-level test hooks
-__global__ void pad_diag_local_kernel(double* K, long ldk, int N, int Npad, int NB, int P, int r) {
-  // ones on the padded diagonal entries (i >= N) that fall into this rank's block columns
+__global__ void pad_diag_local_kernel(double* K, long ldk, int N, int Npad, int OB, int P, int r) {
+  // ones on the padded diagonal entries (i >= N) that fall into this rank's ownership blocks (width OB)
   for (int i = N + blockIdx.x * blockDim.x + threadIdx.x; i < Npad; i += gridDim.x * blockDim.x) {
-    const int g = i / NB;
-    if (g % P == r) K[(long)i * ldk + (long)(g / P) * NB + (i % NB)] = 1.0;
+    const int g = i / OB;
+    if (g % P == r) K[(long)i * ldk + (long)(g / P) * OB + (i % OB)] = 1.0;
   }
 }
 
@@ -789,7 +795,7 @@ int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
   hipStream_t s = G.s_main;
   VirtualJob job;
   GPK_TRY(job.create(N, 1, P));
-  const int NB = job.ms[0]->NB, np_ = job.ms[0]->Npad;
+  const int OB = job.ms[0]->OB, np_ = job.ms[0]->Npad;
   for (int r = 0; r < P; ++r) {
     gpk_model* m = job.ms[r];
     GPK_HIP(hipMemsetAsync(m->dK, 0, (size_t)np_ * m->ldk * 8, s));
@@ -798,14 +804,14 @@ int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
       if (np_ > N) hipLaunchKernelGGL(pad_identity_kernel, dim3(1024), dim3(256), 0, s, m->dK, m->ldk, N, np_);
       continue;
     }
-    for (int lg = 0; lg < m->nloc; ++lg) {
-      const int cg0 = (lg * P + r) * NB;
-      const int nc = std::min(NB, N - cg0);
+    for (int lb = 0; lb < m->nloc; ++lb) {
+      const int cg0 = (lb * P + r) * OB;
+      const int nc = std::min(OB, N - cg0);
       if (nc <= 0) continue;
-      GPK_HIP(hipMemcpy2DAsync(m->dK + (size_t)lg * NB, (size_t)m->ldk * 8, A + cg0, (size_t)N * 8, (size_t)nc * 8, N,
+      GPK_HIP(hipMemcpy2DAsync(m->dK + (size_t)lb * OB, (size_t)m->ldk * 8, A + cg0, (size_t)N * 8, (size_t)nc * 8, N,
                                hipMemcpyHostToDevice, s));
     }
-    if (np_ > N) hipLaunchKernelGGL(pad_diag_local_kernel, dim3(8), dim3(256), 0, s, m->dK, m->ldk, N, np_, NB, P, r);
+    if (np_ > N) hipLaunchKernelGGL(pad_diag_local_kernel, dim3(8), dim3(256), 0, s, m->dK, m->ldk, N, np_, OB, P, r);
   }
   GPK_TRY(P == 1 ? potrf_device(job.ms[0]) : potrf_group(job.ms.data(), P));
   GPK_TRY(virtual_job_check_info(job, N));

@@ -57,13 +57,17 @@ int gpk_comm_init(int rank, int nranks, const void* uid128) {
   G.nccl = c;
   G.rank = rank;
   G.nranks = nranks;
-  // the substitution stream is only used by the single-GPU pipeline; an idle extra high-priority queue is not
-  // free on this part (gpk_init comment), so a multi-rank process runs with three: update, leaf, panel/broadcast
+  // The substitution stream is only used by the single-GPU pipeline, and an idle extra queue is not free on this part
+  // (gpk_init comment): a multi-rank process gives it up and gets the COMMUNICATION stream instead -- the panel
+  // broadcasts run there, off the panel chain (potrf_group), so it still has three: update, panel chain, communication.
   if (G.s_pred && G.s_pred != G.s_panel) {
     (void)hipStreamSynchronize(G.s_pred);
     (void)hipStreamDestroy(G.s_pred);
   }
   G.s_pred = nullptr;
+  int lo = 0, hi = 0;
+  GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  GPK_HIP(hipStreamCreateWithPriority(&G.s_comm, hipStreamNonBlocking, hi));
   return 0;
 }
 
@@ -116,7 +120,7 @@ int gpk_test_rccl_selfcheck(int n_doubles) {
   do {
     if (rc) break;
     if (hipMemcpy(a, h.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    ncclResult_t r = ncclBroadcast(a, a, n, ncclDouble, 0, c, G.s_panel);
+    ncclResult_t r = ncclBroadcast(a, a, n, ncclDouble, 0, c, G.s_pred ? G.s_pred : G.s_panel);  // an unmasked high-priority stream, as the communication stream is
     if (r == ncclSuccess) r = ncclAllGather(a, b, n, ncclDouble, c, G.s_main);
     if (r == ncclSuccess) r = ncclAllReduce(b, b, n, ncclDouble, ncclMax, c, G.s_main);
     if (r != ncclSuccess) { rc = gpk_set_err(-3, "RCCL call failed: %s", ncclGetErrorString(r)); break; }

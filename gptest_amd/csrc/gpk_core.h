@@ -3,6 +3,7 @@
 // the model handle and the blocked-Cholesky driver.
 #pragma once
 #include "gpk_internal.h"
+#include <algorithm>
 #include <functional>
 #include <map>
 
@@ -20,6 +21,7 @@ struct Runtime {
   int device = 0;
   hipStream_t s_main = nullptr, s_panel = nullptr;
   hipStream_t s_pred = nullptr;   // y and prediction substitutions pipelined behind the factorisation (fused fit+predict)
+  hipStream_t s_comm = nullptr;   // multi-rank processes: the panel broadcasts (off the panel chain); virtual ranks use s_pred
   hipStream_t s_rows = nullptr;   // tile pipeline of the chain-bound tail: the full-height panel GEMMs (s_panel keeps the leaves)
   bool cu_reserved = false;
   int ncu_reserved = 8;
@@ -36,6 +38,7 @@ struct Runtime {
   // inner level.  Active for Npad >= outer_from while more than outer_until columns remain; 0 = one level.
   int nb_outer = 2048, outer_from = 1 << 30, outer_until = 4096;  // off by default: measured no gain
   int lookahead = 1;
+  int dist_group = 2;   // panels per ownership block of a block-cyclic (multi-GPU) model
   // tile pipeline (potrf_tail) for the chain-bound last tail_rows columns (needs 128-wide panels there: nb_small_from);
   // 0 = the panel-level look-ahead everywhere
   int tail_rows = 0;
@@ -96,6 +99,21 @@ struct gpk_model {
   // stores only its nloc block columns, side by side, in dK (Npad x ldk).  P = 1: ldk = Npad.
   int P = 1, r = 0, nloc = 0;
   long ldk = 0;
+  // ownership blocks (P > 1): OB = dist_group consecutive panels belong to one rank (global block b -> rank b % P,
+  // local block b / P), so that inside a group the next panel's owner already holds the panel it needs and no
+  // broadcast sits on the panel chain; nloc = number of local ownership blocks, ldk = nloc * OB.  P == 1: OB = Npad.
+  int OB = 0;
+  int owner_of_col(long c) const { return P > 1 ? (int)((c / OB) % P) : 0; }
+  long local_col(long c) const { return P > 1 ? (c / OB / P) * OB + c % OB : c; }   // c must be owned
+  long local_from(long c) const {  // first local column whose global column is >= c (ldk if none)
+    if (P == 1) return c;
+    if (c >= Npad) return ldk;
+    const long b = c / OB;
+    if ((int)(b % P) == r) return (b / P) * OB + c % OB;
+    long nb_ = b + 1;
+    while ((int)(nb_ % P) != r) ++nb_;
+    return std::min<long>(ldk, (nb_ / P) * OB);
+  }
   bool virtual_rank = false;  // single-process emulation of rank r of P (tests): no RCCL calls
   // virtual ranks only: the P rank models of the emulated job, indexed by rank.  The "broadcast" / "all-gather" of a
   // virtual rank is a device copy from the peer's buffers; everything else is the code a real rank runs.
@@ -158,7 +176,7 @@ int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* 
 int build_K(gpk_model* m);                                      // dX -> dK (local block columns)
 int factor_panel(gpk_model* m, int p, hipStream_t s);          // owner only
 int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hipStream_t s);
-int dist_update(gpk_model* m, int p, int first_block, int nblocks_max, hipStream_t s);  // cyclic trailing update
+int dist_update(gpk_model* m, int p, long gc_lo, long gc_hi, hipStream_t s);  // cyclic trailing update of the owned columns in [gc_lo, gc_hi)
 int comm_bcast(double* buf, size_t count, int root, hipStream_t s);
 int comm_allgather(const double* send, double* recv, size_t count, hipStream_t s);
 // prediction for M test points resident at dZ: sharded over the ranks when P > 1 (each rank solves M/P

@@ -147,7 +147,10 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   m->P = P;
   m->r = r;
   if (P > 1 && keep_k) { delete m; return gpk_set_err(-1, "keep-K models are single-GPU only"); }
-  m->Npad = (P > 1) ? round_up(N, nb) : round_up(N, GPK_T);
+  const int group = (P > 1) ? std::max(1, G.dist_group) : 1;
+  m->OB = (P > 1) ? group * nb : 0;
+  m->Npad = (P > 1) ? round_up(N, m->OB) : round_up(N, GPK_T);
+  if (P == 1) m->OB = m->Npad;
   m->nT = m->Npad / GPK_T;
   // panel layout (see gpk_model): inner widths by the remaining size (nb_auto) or uniform nb; outer panels group
   // the inner ones where the two-level schedule applies
@@ -187,9 +190,9 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   m->nP = (int)m->pc0.size();
   m->L_elems = off;
   m->nloc = 0;
-  for (int g = 0; g < m->nP; ++g)
-    if (g % P == r) m->nloc++;
-  m->ldk = (P > 1) ? (long)std::max(m->nloc, 1) * nb : (long)m->Npad;
+  for (int b = 0; b < m->Npad / m->OB; ++b)
+    if (b % P == r) m->nloc++;
+  m->ldk = (P > 1) ? (long)std::max(m->nloc, 1) * m->OB : (long)m->Npad;
   m->keep_k = keep_k;
   const size_t np = m->Npad;
   int rc = 0;
@@ -255,7 +258,7 @@ int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m) {
 int factor_panel(gpk_model* m, int p, hipStream_t s) {
   const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
   const long ldk = m->ldk, ld = m->pld[p];
-  const long kc0 = (m->P > 1) ? (long)(p / m->P) * m->NB : (long)c0;  // local column of global column c0
+  const long kc0 = m->local_col(c0);  // local column of global column c0 (the caller owns panel p)
   double* Lp = m->Lpanel(p);
   const int h = np_ - c0;
   for (int sb = 0; sb < w / 128; ++sb) {
@@ -324,28 +327,35 @@ int outer_update(gpk_model* m, int o, int r0g, int c0g, int ncols, int lower, hi
   return launch_gemm_auto(g, s);
 }
 
-// Distributed trailing update of panel p on THIS rank's block columns: local blocks lg >= first_block
-// (at most nblocks_max of them), rows from the end of panel p's diagonal block.  The kernel maps local
-// tile columns to global columns (GemmNT.cyc_*) for the B-operand rows and the lower-triangle test.
-int dist_update(gpk_model* m, int p, int first_block, int nblocks_max, hipStream_t s) {
+// Distributed trailing update of panel p on THIS rank's columns whose global index lies in [gc_lo, gc_hi), rows from
+// the end of panel p's diagonal block.  The kernel maps local tile columns to global columns (GemmNT.cyc_*) for the
+// B-operand rows and the lower-triangle test.
+int dist_update(gpk_model* m, int p, long gc_lo, long gc_hi, hipStream_t s) {
   const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
   const int r0 = c0 + w;
   const int rows = np_ - r0;
-  int nb_ = m->nloc - first_block;
-  if (nb_ > nblocks_max) nb_ = nblocks_max;
-  if (rows <= 0 || nb_ <= 0) return 0;
+  if (gc_lo < r0) gc_lo = r0;
+  const long lc_lo = m->local_from(gc_lo), lc_hi = m->local_from(gc_hi);
+  if (rows <= 0 || lc_hi <= lc_lo) return 0;
   double* Lp = m->Lpanel(p);
   GemmNT g{};
   g.A = Lp + (long)w * m->pld[p]; g.lda = m->pld[p];
   g.B = g.A; g.ldb = g.lda;
-  g.C = m->dK + (long)r0 * m->ldk + (long)first_block * m->NB; g.ldc = m->ldk;
-  g.m = rows; g.n = nb_ * m->NB; g.k = w; g.sub = 1; g.lower = 1;
-  g.cyc_P = m->P; g.cyc_r = m->r; g.cyc_NB = m->NB; g.cyc_lg0 = first_block;
+  g.C = m->dK + (long)r0 * m->ldk + lc_lo; g.ldc = m->ldk;
+  g.m = rows; g.n = (int)(lc_hi - lc_lo); g.k = w; g.sub = 1; g.lower = 1;
+  g.cyc_P = m->P; g.cyc_r = m->r; g.cyc_NB = m->OB; g.cyc_lg0 = (int)(lc_lo / m->OB); g.cyc_c0 = (int)(lc_lo % m->OB);
   g.row_g0 = r0; g.brow_g0 = r0;
   // a rank's share of an update is 1/P of the tiles: the same latency rule as panel_update (every kernel of
   // k_gemm.hip rounds identically, so the factor does not depend on the choice)
   if ((long)(rows / 128) * (g.n / 128) < G.small_tile_below) return launch_gemm_nt(g, false, s);
   return launch_gemm_nt(g, true, s);
+}
+static double dist_update_flops(const gpk_model* m, int p, long gc_lo, long gc_hi) {
+  double f = 0.0;
+  const long r0 = m->pc0[p] + m->pw[p];
+  for (long c = std::max(gc_lo, r0); c < std::min<long>(gc_hi, m->Npad); c += 128)
+    if (m->owner_of_col(c) == m->r) f += (double)(m->Npad - c) * 128 * m->pw[p];
+  return f;
 }
 
 int model_events(gpk_model* m, int n) {
@@ -696,15 +706,20 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
 // The schedule is written as per-rank phases (dist_*_phase) driven by potrf_group over the rank models that live
 // in this process: one for a real rank, all P for the single-process harness of the tests, whose "broadcast" is a
 // device copy from the owner's model.  Both run the very same phases in the same order.
+static inline int panel_owner(const gpk_model* m, int p) { return m->owner_of_col(m->pc0[p]); }
+// panels are broadcast on a stream of their own, so that the owner's chain goes on while its panel travels:
+// the communication stream of a multi-rank process, the substitution stream in the single-process harness
+static inline hipStream_t comm_stream() { return G.s_comm ? G.s_comm : (G.s_pred ? G.s_pred : G.s_panel); }
+
 static int bcast_panel(gpk_model* m, int p, hipStream_t s) {
-  const int c0 = m->pc0[p], w = m->pw[p], owner = p % m->P;
+  const int c0 = m->pc0[p], w = m->pw[p], owner = panel_owner(m, p);
   const size_t cnt = (size_t)(m->Npad - c0) * w;
   const size_t dcnt = (size_t)(w / 128) * 128 * 128;
   double* dinv = m->dDinv + (size_t)(c0 / 128) * 128 * 128;
   if (m->virtual_rank) {
     if (!m->vgroup) return gpk_set_err(-1, "internal: virtual rank %d without a group", m->r);
     if (owner == m->r) return 0;
-    const gpk_model* o = m->vgroup[owner];  // the owner's phase was queued on this stream before ours (potrf_group)
+    const gpk_model* o = m->vgroup[owner];  // the caller has made `s` wait for the owner's factorisation of panel p
     GPK_HIP(hipMemcpyAsync(m->Lpanel(p), o->Lpanel(p), cnt * 8, hipMemcpyDeviceToDevice, s));
     GPK_HIP(hipMemcpyAsync(dinv, o->dDinv + (size_t)(c0 / 128) * 128 * 128, dcnt * 8, hipMemcpyDeviceToDevice, s));
     return 0;
@@ -713,82 +728,88 @@ static int bcast_panel(gpk_model* m, int p, hipStream_t s) {
   GPK_TRY(comm_bcast(dinv, dcnt, owner, s));
   return 0;
 }
-static double dist_update_flops(const gpk_model* m, int p, int first_block, int nblocks_max) {
-  double f = 0.0;
-  int cnt = 0;
-  for (int lg = first_block; lg < m->nloc && cnt < nblocks_max; ++lg, ++cnt) {
-    const long g = (long)lg * m->P + m->r;
-    f += (double)(m->Npad - g * m->NB) * m->NB * m->pw[p];
-  }
-  return f;
-}
-static inline int first_local_block_after(const gpk_model* m, int p) {  // # local blocks with global index <= p
-  return (p >= m->r) ? (p - m->r) / m->P + 1 : 0;
-}
 static inline bool dist_lookahead(const gpk_model* m) { return G.lookahead && m->nP >= 3; }
 
-// ---- look-ahead schedule, one rank.  Events: ev[p] = panel p available on this rank (s_panel),
-//      ev[nP + p] = rest-update of step p done (s_main), ev[2 nP] = start.
-static int dist_la_begin(gpk_model* m) {
-  hipStream_t sm = G.s_main, sp = G.s_panel;
-  const int nP = m->nP;
-  GPK_TRY(model_events(m, 3 * nP + 6));
-  GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
-  GPK_HIP(hipEventRecord(m->ev[2 * nP], sm));  // s_panel must not start before the K build queued on s_main
-  GPK_HIP(hipStreamWaitEvent(sp, m->ev[2 * nP], 0));
-  if (0 % m->P == m->r) GPK_TRY(factor_panel(m, 0, sp));
-  GPK_TRY(bcast_panel(m, 0, sp));
-  GPK_HIP(hipEventRecord(m->ev[0], sp));
+// ---- look-ahead schedule, one rank.  Events of rank model m: ev[p] = panel p AVAILABLE on this rank (the owner: its
+//      factorisation on s_panel; the others: the broadcast on the communication stream), ev[nP + p] = update p of the
+//      columns right of the look-ahead column done (s_main), ev[2 nP] = start, ev[2 nP + 6 + p] = broadcast of panel
+//      p finished on this rank (communication stream; only ordering between broadcasts and the final join need it).
+static int dist_publish_panel(gpk_model* m, int p) {
+  // every rank takes part in the broadcast of panel p, in panel order, on the communication stream
+  hipStream_t sp = G.s_panel, sc = comm_stream();
+  hipEvent_t* ev_avail = m->ev.data();
+  hipEvent_t* ev_bcast = m->ev.data() + 2 * m->nP + 6;
+  const int owner = panel_owner(m, p);
+  if (owner == m->r) {
+    GPK_HIP(hipEventRecord(ev_avail[p], sp));               // factored here: available at once
+    GPK_HIP(hipStreamWaitEvent(sc, ev_avail[p], 0));
+  } else if (m->virtual_rank) {
+    GPK_HIP(hipStreamWaitEvent(sc, m->vgroup[owner]->ev[p], 0));  // the copy reads the owner's buffers
+  }
+  GPK_TRY(bcast_panel(m, p, sc));
+  GPK_HIP(hipEventRecord(ev_bcast[p], sc));
+  if (owner != m->r) GPK_HIP(hipEventRecord(ev_avail[p], sc));  // received
   return 0;
 }
-// panel phase of step p (s_panel): panel p+1 becomes available on this rank
+static int dist_la_begin(gpk_model* m) {
+  hipStream_t sm = G.s_main, sp = G.s_panel, sc = comm_stream();
+  const int nP = m->nP;
+  GPK_TRY(model_events(m, 3 * nP + 8));
+  GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
+  GPK_HIP(hipEventRecord(m->ev[2 * nP], sm));  // nothing may start before the K build queued on s_main
+  GPK_HIP(hipStreamWaitEvent(sp, m->ev[2 * nP], 0));
+  GPK_HIP(hipStreamWaitEvent(sc, m->ev[2 * nP], 0));
+  if (panel_owner(m, 0) == m->r) GPK_TRY(factor_panel(m, 0, sp));
+  return dist_publish_panel(m, 0);
+}
+// panel phase of step p: panel p+1 becomes available on this rank
 static int dist_la_panel_phase(gpk_model* m, int p) {
   hipStream_t sp = G.s_panel;
   const int nP = m->nP;
   if (p + 1 >= nP) return 0;
-  hipEvent_t* ev_panel = m->ev.data();
+  hipEvent_t* ev_avail = m->ev.data();
   hipEvent_t* ev_trail = m->ev.data() + nP;
-  if ((p + 1) % m->P == m->r) {  // block column p+1 is my local block lg0 (the first one after p)
-    const int lg0 = first_local_block_after(m, p);
-    if (p > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[p - 1], 0));  // its earlier updates ran on s_main
-    GPK_TRY(dist_update(m, p, lg0, 1, sp));
+  if (panel_owner(m, p + 1) == m->r) {
+    const long c1 = m->pc0[p + 1];
+    if (p > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[p - 1], 0));  // earlier updates of that column ran on s_main
+    GPK_HIP(hipStreamWaitEvent(sp, ev_avail[p], 0));                   // panel p: own factorisation or received
+    GPK_TRY(dist_update(m, p, c1, c1 + m->pw[p + 1], sp));
     GPK_TRY(factor_panel(m, p + 1, sp));
   }
-  GPK_TRY(bcast_panel(m, p + 1, sp));  // every rank takes part
-  GPK_HIP(hipEventRecord(ev_panel[p + 1], sp));
-  return 0;
+  return dist_publish_panel(m, p + 1);
 }
-// update phase of step p (s_main): every local block column right of the look-ahead column gets update p
+// update phase of step p (s_main): every owned column right of the look-ahead column gets update p
 static int dist_la_update_phase(gpk_model* m, int p) {
   hipStream_t sm = G.s_main;
   const int nP = m->nP;
-  hipEvent_t* ev_panel = m->ev.data();
+  hipEvent_t* ev_avail = m->ev.data();
   hipEvent_t* ev_trail = m->ev.data() + nP;
-  const int lg0 = first_local_block_after(m, p);
-  const bool own_next = (p + 1 < nP) && ((p + 1) % m->P == m->r);
-  GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
-  timer_begin("trailing", sm, dist_update_flops(m, p, lg0 + (own_next ? 1 : 0), 1 << 30));
-  GPK_TRY(dist_update(m, p, lg0 + (own_next ? 1 : 0), 1 << 30, sm));
+  const long from = (p + 1 < nP) ? m->pc0[p + 1] + m->pw[p + 1] : m->Npad;  // the look-ahead column is the chain's
+  GPK_HIP(hipStreamWaitEvent(sm, ev_avail[p], 0));
+  timer_begin("trailing", sm, dist_update_flops(m, p, from, m->Npad));
+  GPK_TRY(dist_update(m, p, from, m->Npad, sm));
   timer_end("trailing", sm);
   GPK_HIP(hipEventRecord(ev_trail[p], sm));
   return 0;
 }
 static int dist_la_end(gpk_model* m) {
-  GPK_HIP(hipStreamWaitEvent(G.s_main, m->ev[m->nP - 1], 0));  // everything after potrf runs on s_main
+  // everything after potrf runs on s_main: the last panel must be here and the communication stream drained
+  GPK_HIP(hipStreamWaitEvent(G.s_main, m->ev[m->nP - 1], 0));
+  GPK_HIP(hipStreamWaitEvent(G.s_main, m->ev[2 * m->nP + 6 + m->nP - 1], 0));
   return 0;
 }
 // ---- no look-ahead (option lookahead = 0, or fewer than three panels): everything on s_main
 static int dist_plain_panel_phase(gpk_model* m, int p) {
   hipStream_t sm = G.s_main;
   if (p == 0) GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
-  if (p % m->P == m->r) GPK_TRY(factor_panel(m, p, sm));
+  if (panel_owner(m, p) == m->r) GPK_TRY(factor_panel(m, p, sm));
   return bcast_panel(m, p, sm);
 }
 static int dist_plain_update_phase(gpk_model* m, int p) {
   hipStream_t sm = G.s_main;
-  const int lg0 = first_local_block_after(m, p);
-  timer_begin("trailing", sm, dist_update_flops(m, p, lg0, 1 << 30));
-  GPK_TRY(dist_update(m, p, lg0, 1 << 30, sm));
+  const long from = m->pc0[p] + m->pw[p];
+  timer_begin("trailing", sm, dist_update_flops(m, p, from, m->Npad));
+  GPK_TRY(dist_update(m, p, from, m->Npad, sm));
   timer_end("trailing", sm);
   return 0;
 }
@@ -803,7 +824,7 @@ int potrf_group(gpk_model* const* ms, int n) {
   const int nP = ms[0]->nP, P = ms[0]->P;
   for (int i = 0; i < n; ++i) {
     const gpk_model* m = ms[i];
-    if (m->P != P || m->nP != nP || m->Npad != ms[0]->Npad)
+    if (m->P != P || m->nP != nP || m->Npad != ms[0]->Npad || m->OB != ms[0]->OB)
       return gpk_set_err(-1, "potrf_group: rank models disagree on the block-cyclic layout");
     if (n > 1 && (!m->virtual_rank || n != P || m->r != i || m->vgroup != ms))
       return gpk_set_err(-1, "potrf_group: a group of %d needs the %d virtual ranks in rank order", n, P);
@@ -817,14 +838,14 @@ int potrf_group(gpk_model* const* ms, int n) {
   g_dist_lookahead_used = la ? 1 : 0;
   if (!la) {
     for (int p = 0; p < nP; ++p) {
-      GPK_TRY(from_owner(p % P, [&](gpk_model* m) { return dist_plain_panel_phase(m, p); }));
+      GPK_TRY(from_owner(panel_owner(ms[0], p), [&](gpk_model* m) { return dist_plain_panel_phase(m, p); }));
       GPK_TRY(from_owner(0, [&](gpk_model* m) { return dist_plain_update_phase(m, p); }));
     }
     return 0;
   }
   GPK_TRY(from_owner(0, [&](gpk_model* m) { return dist_la_begin(m); }));
   for (int p = 0; p < nP; ++p) {
-    GPK_TRY(from_owner((p + 1) % P, [&](gpk_model* m) { return dist_la_panel_phase(m, p); }));
+    GPK_TRY(from_owner(p + 1 < nP ? panel_owner(ms[0], p + 1) : 0, [&](gpk_model* m) { return dist_la_panel_phase(m, p); }));
     GPK_TRY(from_owner(0, [&](gpk_model* m) { return dist_la_update_phase(m, p); }));
   }
   GPK_TRY(from_owner(0, [&](gpk_model* m) { return dist_la_end(m); }));
@@ -837,15 +858,14 @@ int build_K(gpk_model* m) {
   const int np_ = m->Npad;
   if (m->P == 1)
     return launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, np_, m->keep_k ? 0 : 1, s);
-  for (int lg = 0; lg < m->nloc; ++lg) {
-    const int g = lg * m->P + m->r;
-    const int cg0 = g * m->NB;
+  for (int lb = 0; lb < m->nloc; ++lb) {  // one launch per owned ownership block
+    const int cg0 = (lb * m->P + m->r) * m->OB;
     int nc = m->N - cg0;
-    if (nc > m->NB) nc = m->NB;
+    if (nc > m->OB) nc = m->OB;
     if (nc < 0) nc = 0;
     // column points of this block (clamped pointer: nc == 0 blocks are pure padding)
     const double* Cc = m->dX + (size_t)(nc > 0 ? cg0 : 0) * m->d;
-    GPK_TRY(launch_se_build(m->dX, m->N, np_, Cc, nc, m->NB, m->se, 1, 0, m->dK + (size_t)lg * m->NB, m->ldk, 1, s, cg0));
+    GPK_TRY(launch_se_build(m->dX, m->N, np_, Cc, nc, m->OB, m->se, 1, 0, m->dK + (size_t)lb * m->OB, m->ldk, 1, s, cg0));
   }
   return 0;
 }

@@ -38,8 +38,9 @@ struct GemmNT {
   int m, n, k;
   int sub;    // 0: C = A*B^T      1: C = C - A*B^T
   int lower;  // 1: compute only tiles that touch the lower triangle (global row >= global col)
-  // block-cyclic column map (multi-GPU trailing update). cyc_P == 0 -> identity map.
-  int cyc_P, cyc_r, cyc_NB, cyc_lg0;
+  // block-cyclic column map (multi-GPU trailing update). cyc_P == 0 -> identity map.  C column 0 is local column
+  // cyc_lg0 * cyc_NB + cyc_c0 of this rank; local ownership block b holds global columns ((b * P + r) * NB ...).
+  int cyc_P, cyc_r, cyc_NB, cyc_lg0, cyc_c0;
   long row_g0;   // global row index of C row 0
   long brow_g0;  // global row index of B row 0 (B tile row = gcol(tj) - brow_g0 when cyc_P > 0 or lower)
   int xcd_sq;    // 8-wave kernel: XCD-aware 8x8-tile square order (single GPU)

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
   long brow0;  // first row of the B tile
   if (g.cyc_P > 0) {
     const int tpb = g.cyc_NB / BT;
-    long gcol = ((long)(tj / tpb + g.cyc_lg0) * g.cyc_P + g.cyc_r) * g.cyc_NB + (long)(tj % tpb) * BT;
+    const int t = tj + g.cyc_c0 / BT;
+    long gcol = ((long)(t / tpb + g.cyc_lg0) * g.cyc_P + g.cyc_r) * g.cyc_NB + (long)(t % tpb) * BT;
     if (g.lower && gcol > g.row_g0 + (long)ti * BT) return;  // tile entirely above the diagonal
     brow0 = gcol - g.brow_g0;
   } else {
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   long brow0;
   if (g.cyc_P > 0) {
     const int tpb = g.cyc_NB / BT;
-    long gcol = ((long)(tj / tpb + g.cyc_lg0) * g.cyc_P + g.cyc_r) * g.cyc_NB + (long)(tj % tpb) * BT;
+    const int t = tj + g.cyc_c0 / BT;
+    long gcol = ((long)(t / tpb + g.cyc_lg0) * g.cyc_P + g.cyc_r) * g.cyc_NB + (long)(t % tpb) * BT;
     if (g.lower && gcol > g.row_g0 + (long)ti * BT) return;
     brow0 = gcol - g.brow_g0;
   } else {

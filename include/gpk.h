@@ -43,7 +43,9 @@ double      gpk_get_option(const char* key);
 /* rank 0 calls gpk_comm_unique_id, the host broadcasts the 128 bytes by any
  * means (gptest_amd/dist.py: a plain TCP socket next to MASTER_PORT), every rank
  * calls gpk_comm_init.  A multi-rank process gives up the substitution stream
- * of the single-GPU pipeline (block-cyclic models never use it).            */
+ * of the single-GPU pipeline (block-cyclic models never use it) for a
+ * communication stream: the panel broadcasts run there, off the panel chain.
+ * Option "dist_group": panels per ownership block (default 2).              */
 int gpk_comm_unique_id(void* out128);
 int gpk_comm_init(int rank, int nranks, const void* uid128);
 int gpk_comm_rank(void);

@@ -25,7 +25,8 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t) {
       long brow0;
       if (g.cyc_P > 0) {
         const int tpb = g.cyc_NB / BT;
-        const long gcol = ((long)(tj / tpb + g.cyc_lg0) * g.cyc_P + g.cyc_r) * g.cyc_NB + (long)(tj % tpb) * BT;
+        const int t = tj + g.cyc_c0 / BT;
+        const long gcol = ((long)(t / tpb + g.cyc_lg0) * g.cyc_P + g.cyc_r) * g.cyc_NB + (long)(t % tpb) * BT;
         if (g.lower && gcol > g.row_g0 + (long)ti * BT) continue;
         brow0 = gcol - g.brow_g0;
       } else {

@@ -156,8 +156,9 @@ int main() {
   opt("nb_outer", 2048); opt("outer_from", 1 << 30); opt("outer_until", 4096); opt("nb_big", 512); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
 
   // ---- block-cyclic schedule on virtual ranks (look-ahead and plain), against the one-rank factor
-  for (int la : {1, 0}) {
+  for (int la : {1, 0}) for (int grp : {1, 2, 3}) {
     opt("lookahead", la);
+    opt("dist_group", grp);
     opt("nb", 128);
     const int N = 700;
     vec A((size_t)N * N);
@@ -167,10 +168,11 @@ int main() {
     for (int P : {2, 3, 4, 8}) {
       CHECK(gpk_test_dist_potrf(A.data(), N, P, LP.data()) == 0, "dist P=%d la=%d", P, la);
       CHECK(gpk_get_option("dist_lookahead_used") == la, "look-ahead branch P=%d", P);
-      CHECK(maxdiff(L1, LP) <= 1e-11, "dist P=%d la=%d diff %g", P, la, maxdiff(L1, LP));
+      CHECK(maxdiff(L1, LP) <= 1e-11, "dist P=%d la=%d group=%d diff %g", P, la, grp, maxdiff(L1, LP));
     }
   }
   opt("lookahead", 1);
+  opt("dist_group", 2);
   {
     Problem p = make_problem(900, 3, 70);
     const Posterior ref = dense_posterior(p, p.N);

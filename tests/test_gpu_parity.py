@@ -434,12 +434,13 @@ def test_full_size_properties_c3(gpk):
 
 
 # ----------------------------------------------------------------------------- multi-GPU logic on one GPU
-@pytest.mark.parametrize("lookahead", [1, 0])
+@pytest.mark.parametrize("lookahead,group", [(1, 1), (1, 2), (1, 3), (0, 2)])
 @pytest.mark.parametrize("N,P,nb", [(700, 2, 128), (1500, 2, 256), (1500, 3, 256), (2048, 4, 256), (2500, 8, 128), (3000, 8, 256)])
-def test_block_cyclic_cholesky_emulated_ranks(gpk, N, P, nb, lookahead):
+def test_block_cyclic_cholesky_emulated_ranks(gpk, N, P, nb, lookahead, group):
     """P "virtual ranks" in one process are driven through the PRODUCTION schedule (potrf_group: the
-    per-rank panel phase on the panel stream, update phase on the update stream, per-rank events, one panel of
-    look-ahead) -- the code a real rank runs; only the RCCL broadcast is a device copy from the owner's model.  The
+    per-rank panel phase on the panel stream, update phase on the update stream, broadcasts on the communication
+    stream, per-rank events, one panel of look-ahead, ownership blocks of `group` panels) -- the code a real rank
+    runs; only the RCCL broadcast is a device copy from the owner's model.  The
     factor must equal the one-GPU production factor with the same panel width bit for bit (same kernels, same
     summation order per element) and NumPy's."""
     rng = np.random.RandomState(N + P)
@@ -447,6 +448,7 @@ def test_block_cyclic_cholesky_emulated_ranks(gpk, N, P, nb, lookahead):
     A = Q @ Q.T + N * np.eye(N)
     gpk.set_option("nb", nb)
     gpk.set_option("lookahead", lookahead)
+    gpk.set_option("dist_group", group)   # panels per ownership block (1: every panel changes hands)
     L1 = np.empty((N, N))
     assert gpk.lib().gpk_test_dist_potrf(_ptr(A), N, 1, _ptr(L1)) == 0, gpk.last_error()
     LP = np.empty((N, N))
@@ -458,8 +460,9 @@ def test_block_cyclic_cholesky_emulated_ranks(gpk, N, P, nb, lookahead):
     np.testing.assert_array_equal(LP, L1)
 
 
-@pytest.mark.parametrize("N,d,M,P,nb", [(1000, 3, 100, 2, 256), (2048, 4, 300, 4, 128), (3000, 8, 1024, 8, 256), (1500, 2, 5, 8, 128)])
-def test_block_cyclic_posterior_emulated_ranks(gpk, N, d, M, P, nb):
+@pytest.mark.parametrize("N,d,M,P,nb,group", [(1000, 3, 100, 2, 256, 2), (2048, 4, 300, 4, 128, 1), (3000, 8, 1024, 8, 256, 2),
+                                              (1500, 2, 5, 8, 128, 4), (2600, 3, 130, 3, 128, 3)])
+def test_block_cyclic_posterior_emulated_ranks(gpk, N, d, M, P, nb, group):
     """The whole P-rank posterior on virtual ranks: fit_group (K built per rank in its block columns, look-ahead
     factorisation, redundant y substitution) + predict_group (test points sharded over the ranks, all-gather
     emulated by device copies).  Every rank must end with the same result, equal to the one-GPU posterior within
@@ -469,6 +472,7 @@ def test_block_cyclic_posterior_emulated_ranks(gpk, N, d, M, P, nb):
 
     X, y, Z, lh = orc.synthetic_problem(N, d, M)
     gpk.set_option("nb", nb)
+    gpk.set_option("dist_group", group)
     nl = np.zeros(P)
     mean = np.zeros((P, M))
     var = np.zeros((P, M))
