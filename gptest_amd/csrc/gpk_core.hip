@@ -1053,6 +1053,8 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   GPK_TRY(potrf_device(m, (pipelined && G.pipe_interleave) ? &hook : nullptr));
   G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   timer_end("potrf", s);
+  // s_main has joined the last panel: the log-determinant can run while the substitution stream finishes
+  GPK_TRY(launch_sum_log_diag(m->dDinv, m->N, m->dscal + 0, s));
   const auto host_t1 = std::chrono::steady_clock::now();
   if (pipelined) {
     if (!g_potrf_lookahead_used) return gpk_set_err(-1, "internal: pipelined substitutions without look-ahead");
@@ -1072,7 +1074,6 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     }
   }
   G.last_pipe_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count();
-  GPK_TRY(launch_sum_log_diag(m->dDinv, m->N, m->dscal + 0, s));
   if (m->has_y) {
     timer_begin("solve_y", s);
     if (!pipelined) {

@@ -2,7 +2,8 @@
 Cholesky with 1-D block-cyclic column ownership and one broadcast of the factored panel per step
 (SURVEY.md 8e).  The reference has no distributed code; this exists so the N>1 schedule can be checked on
 CPU over gloo (tests/test_dist_gloo.py).  Each rank holds only its own block columns of A plus the
-panels it received, exactly like gptest_amd/csrc/gpk_core.hip: potrf_distributed."""
+panels it received, exactly like gptest_amd/csrc/gpk_core.hip: potrf_group; `group` consecutive panels form one
+ownership block (gpk_model::OB, option dist_group): panel g belongs to rank (g // group) % world."""
 import numpy as np
 
 
@@ -15,23 +16,27 @@ def torch_bcast(arr, root):
     return t.numpy()
 
 
-def cholesky_block_cyclic(A, nb, rank, world, bcast):
+def cholesky_block_cyclic(A, nb, rank, world, bcast, group=1):
     N = A.shape[0]
     nP = (N + nb - 1) // nb
-    mine = [g for g in range(nP) if g % world == rank]
+
+    def owner(g):
+        return (g // group) % world
+
+    mine = [g for g in range(nP) if owner(g) == rank]
     local = {g: A[:, g * nb:min(N, (g + 1) * nb)].copy() for g in mine}  # my block columns (all rows)
     L = np.zeros_like(A)
     for p in range(nP):
         c0, c1 = p * nb, min(N, (p + 1) * nb)
         w = c1 - c0
         panel = np.empty((N - c0, w))
-        if p % world == rank:
+        if owner(p) == rank:
             blk = local[p]
             L11 = np.linalg.cholesky(blk[c0:c1, :])
             panel[:w] = L11
             if c1 < N:  # L21 = A21 * inv(L11)^T, the inverse applied as a product like the GPU path
                 panel[w:] = blk[c1:, :] @ np.linalg.inv(L11).T
-        panel = bcast(panel, p % world)
+        panel = bcast(panel, owner(p))
         L[c0:, c0:c1] = panel
         P21 = panel[w:]
         for g in mine:

@@ -55,9 +55,10 @@ WORKER = textwrap.dedent(
     N, nb = 200, 32
     Q = rng.randn(N, N)
     A = Q @ Q.T + N * np.eye(N)
-    L = dco.cholesky_block_cyclic(A, nb, rank, world, dco.torch_bcast)
     ref = np.linalg.cholesky(A)
-    assert np.allclose(L, ref, rtol=1e-11, atol=1e-11), np.abs(L - ref).max()
+    for group in (1, 2, 3):   # panels per ownership block (libgpk option dist_group)
+        L = dco.cholesky_block_cyclic(A, nb, rank, world, dco.torch_bcast, group=group)
+        assert np.allclose(L, ref, rtol=1e-11, atol=1e-11), (group, np.abs(L - ref).max())
     tdist.barrier()
     tdist.destroy_process_group()
     sys.stdout.write("rank " + str(rank) + " ok" + chr(10))  # one write(): atomic on the shared pipe
