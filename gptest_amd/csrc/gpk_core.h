@@ -36,7 +36,7 @@ struct Runtime {
   // ONE update with K = nb_outer (the kernel does 56 TFLOP/s at K = 2048 against 44 at K = 256: the C tile traffic
   // and the accumulator hand-over amortise over 8x the flops); inside an outer block column the panels above are the
   // inner level.  Active for Npad >= outer_from while more than outer_until columns remain; 0 = one level.
-  int nb_outer = 2048, outer_from = 1 << 30, outer_until = 4096;  // off by default: measured no gain
+  int nb_outer = 2048, outer_from = 24576, outer_until = 8192;  // N = 16384: no gain; N = 32768: 230.6 -> 225.2 ms
   int lookahead = 1;
   int dist_group = 2;   // panels per ownership block of a block-cyclic (multi-GPU) model
   // tile pipeline (potrf_tail) for the chain-bound last tail_rows columns (needs 128-wide panels there: nb_small_from);

@@ -153,7 +153,7 @@ int main() {
   CHECK(gpk_get_option("potrf_tail_from") == 0, "tile pipeline from panel 0");
   check_fit_predict(make_problem(300, 1, 5), "tile pipeline, three tiles");
   opt("tail_rows", 0); opt("nb", 256); opt("nb_auto", 1);
-  opt("nb_outer", 2048); opt("outer_from", 1 << 30); opt("outer_until", 4096); opt("nb_big", 512); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
+  opt("nb_outer", 2048); opt("outer_from", 24576); opt("outer_until", 8192); opt("nb_big", 512); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
 
   // ---- block-cyclic schedule on virtual ranks (look-ahead and plain), against the one-rank factor
   for (int la : {1, 0}) for (int grp : {1, 2, 3}) {
