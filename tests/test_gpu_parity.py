@@ -1068,6 +1068,19 @@ def test_gpy_compat_growing_model_flow(gpk):
     np.testing.assert_allclose(kernel.K(X[:30]), 10. * np.exp(-0.5 * orc.squared_distance(X[:30] / 20., X[:30] / 20.)), rtol=1e-12)
 
 
+def test_parameter_fit_demo_flow(gpk):
+    """examples/gp_parameter_fit_demo.py = GP_parameter_fit.py without the plotting, through dropin/GPy."""
+    import importlib.util
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("gp_parameter_fit_demo", os.path.join(ROOT, "examples", "gp_parameter_fit_demo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(verbose=False, n_points=120, frames=25)
+    assert r["appended"] == 24 and len(r["rmse"]) == 25
+    assert r["rmse"][-1] < r["rmse"][0] and np.all(np.isfinite(r["rmse"]))
+
+
 def test_gpy_compat_optimize_uses_the_device_gradient(gpk):
     from gptest_amd import gpy_compat as GPy_
     from oracle import gpr_oracle as orc
