@@ -7,7 +7,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gptest_amd import _lib  # noqa: E402
-from oracle.gpr_oracle import synthetic_problem  # noqa: E402  (input generator only)
+from bench import synthetic_problem  # noqa: E402  (the bench's own input generator)
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 8

@@ -3,7 +3,7 @@ import ctypes, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gptest_amd import _lib
-from oracle.gpr_oracle import synthetic_problem
+from bench import synthetic_problem
 N, d, M = 4096, 4, 1024
 args = sys.argv[1:]
 if args and args[0].isdigit():
