@@ -913,6 +913,25 @@ def test_gpc_laplace_matches_oracle(gpk, n, d, link, seed):
     assert np.all(prob > 0) and np.all(prob < 1) and np.all(var > -1e-9)
 
 
+def test_gpc_far_start_uses_the_stable_probit_tail(gpk):
+    """Start the Newton loop far on the wrong side (z = y f = -20 ... -60, where Phi underflows towards 0): the device
+    statistics take the erfcx branch; the iteration trace and the mode must still follow the oracle's."""
+    from gptest_amd import GPc
+    from oracle import gpc_oracle as co
+
+    x, y = co.demo_problem(n_train=150, seed=11, d=2)
+    lh = np.log([0.3, 0.3, 2.0])
+    f0 = -(20.0 + 40.0 * np.random.RandomState(0).rand(150)) * y
+    gp = GPc.ClassificationGaussianProcess(x, y, delta_f=1e-8)
+    f, lml = gp.calc_laplace(lh, f=f0)
+    tr = []
+    fo, lo, it = co.calc_laplace(x, y, lh, delta_f=1e-8, f=f0, trace=tr)
+    assert gp.last_converged and abs(gp.last_iterations - it) <= 1
+    np.testing.assert_allclose(gp.last_trace[:3], tr[:3], rtol=1e-6)
+    np.testing.assert_allclose(f.ravel(), fo, rtol=0, atol=1e-6 * np.abs(fo).max())
+    assert abs(lml - lo) <= 1e-6 * abs(lo)
+
+
 def test_gpc_surface_and_label_handling(gpk):
     """{0,1} labels are mapped to {-1,+1} as GPc.py:24-38 prescribes; anything else is refused; the likelihood
     helpers agree with the oracle; the mode satisfies f = K grad log p(y|f) (R&W eq. 3.17), a property that does not
