@@ -208,6 +208,20 @@ def main():
                                 % (os.path.basename(newest), tj["launches"], tj["algorithmic_bytes_per_launch"]))
         except Exception:
             pass
+        mfma_pmc = None
+        try:
+            import glob
+
+            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util_gemm_nt8.json")))[-1]) as fh:
+                mj = json.load(fh)
+            if world == 1 and N == 16384:
+                mfma_pmc = {"mfma_util_percent": mj["mfma_util_percent"], "shader_clock_ghz": mj["shader_clock_ghz"],
+                            "tflops": mj["tflops_in_this_pass"],
+                            "note": "committed rocprofv3 --pmc pass of this command (SQ_VALU_MFMA_BUSY_CYCLES, "
+                                    "SQ_INSTS_VALU_MFMA_MOPS_F64, GRBM_GUI_ACTIVE); counter collection serialises dispatches, so "
+                                    "these launches ran ALONE there, not next to the panel chain and the prediction"}
+        except Exception:
+            pass
         flops = tr_flops / max(args.steps, 1)
         out = {
             "metric": "GP posterior solves/sec (N=%d, d=%d, M=%d; fit + predict sharing one Cholesky)" % (N, d, M),
@@ -230,6 +244,7 @@ def main():
             "roofline": {"kernel": "gemm_nt8_kernel (Cholesky trailing update, fp64 MFMA 16x16x4)", "bound": "mfma",
                          "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                         "mfma_pmc_serialised": mfma_pmc,
                          "launches": tr_n, "avg_launch_ms": tr_ms / tr_n if tr_n else None,
                          "alg_flops_per_step_in_timed_launches": flops},
             "kbuild": {"kernel": "se_build_kernel", "bound": "hbm", "ms": kb_ms / kb_n if kb_n else None, "unit": "GB/s",
