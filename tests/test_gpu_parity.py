@@ -1173,3 +1173,36 @@ def test_rccl_calls_on_a_one_rank_communicator(gpk):
     """All a 1-GPU box can check of gpk_comm.hip: panel-sized ncclBroadcast on the panel stream, ncclAllGather and
     ncclAllReduce on the CU-masked update stream, on a one-rank communicator, payload intact."""
     assert gpk.lib().gpk_test_rccl_selfcheck(16384 * 256) == 0, gpk.last_error()
+
+
+# ----------------------------------------------------------------------------- process teardown (round-1 verdict item 6)
+def test_shutdown_reinit_and_clean_process_exit(gpk):
+    """A child process runs the pattern that used to hang at exit (heavy use of the CU-masked update stream only, then
+    shutdown -- explicit, and again from the interpreter-exit handler after a re-init) and must END by itself with
+    status 0: gpk_shutdown leaves the masked stream to process teardown (scripts/shutdown_probe.py has the matrix)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+
+    code = """
+import ctypes, sys
+sys.path.insert(0, %r)
+import numpy as np
+from gptest_amd import _lib, GPr
+_lib.init()
+l = _lib.lib()
+ms = ctypes.c_double()
+for lower in (1, 0, 1, 0):
+    assert l.gpk_bench_se_build(4096, 8, 0, lower, 5, ctypes.byref(ms)) == 0
+_lib.shutdown()                                  # explicit: everything but the masked stream is destroyed
+rng = np.random.RandomState(0)
+X = rng.rand(700, 2); y = rng.randn(700); lh = np.log([0.5, 0.5, 1.0, 0.1])
+h, nl = GPr.fit_handle(X, y, lh)                 # re-initialises, reusing the parked stream
+assert np.isfinite(nl)
+for lower in (1, 0):
+    assert l.gpk_bench_se_build(4096, 8, 0, lower, 5, ctypes.byref(ms)) == 0
+print("child done", flush=True)                  # the interpreter-exit handler shuts down again
+""" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert "child done" in p.stdout, p.stdout[-2000:]
+    assert p.returncode == 0, p.stdout[-2000:]
