@@ -227,6 +227,9 @@ int gpk_set_option(const char* key, double value) {
     G.nb_outer = (int)value;
   } else if (k == "lookahead") {
     G.lookahead = (int)value;
+  } else if (k == "ldk_pad") {
+    if ((int)value < 0 || (int)value > 4096 || ((int)value & 1)) return gpk_set_err(-1, "ldk_pad must be an even number in 0..4096");
+    G.ldk_pad = (int)value;
   } else if (k == "dist_group") {
     if ((int)value < 1 || (int)value > 64) return gpk_set_err(-1, "dist_group must be in 1..64");
     G.dist_group = (int)value;
@@ -280,6 +283,7 @@ double gpk_get_option(const char* key) {
   if (k == "nb") return G.nb;
   if (k == "lookahead") return G.lookahead;
   if (k == "dist_group") return G.dist_group;
+  if (k == "ldk_pad") return G.ldk_pad;
   if (k == "timing") return G.timing;
   if (k == "pool_bytes") return (double)G.pool_bytes;
   if (k == "potrf_enqueue_ms") return G.last_potrf_enqueue_ms;
@@ -399,8 +403,8 @@ int gpk_potrf(double* A, int N) {
   hipStream_t s = G.s_main;
   int rc = 0;
   do {
-    if (hipMemcpy2DAsync(m->dK, (size_t)m->Npad * 8, A, (size_t)N * 8, (size_t)N * 8, N, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    if (m->Npad != N) hipLaunchKernelGGL(pad_identity_kernel, dim3(1024), dim3(256), 0, s, m->dK, (long)m->Npad, N, m->Npad);
+    if (hipMemcpy2DAsync(m->dK, (size_t)m->ldk * 8, A, (size_t)N * 8, (size_t)N * 8, N, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
+    if (m->Npad != N) hipLaunchKernelGGL(pad_identity_kernel, dim3(1024), dim3(256), 0, s, m->dK, m->ldk, N, m->Npad);
     rc = potrf_device(m);
     if (rc) break;
     int hinfo = 0;

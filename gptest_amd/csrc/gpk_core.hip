@@ -192,7 +192,8 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   m->nloc = 0;
   for (int b = 0; b < m->Npad / m->OB; ++b)
     if (b % P == r) m->nloc++;
-  m->ldk = (P > 1) ? (long)std::max(m->nloc, 1) * m->OB : (long)m->Npad;
+  // P == 1: rows of K are Npad + ldk_pad doubles apart (a power-of-two row stride aliases HBM channels: option ldk_pad)
+  m->ldk = (P > 1) ? (long)std::max(m->nloc, 1) * m->OB : (long)m->Npad + (G.ldk_pad / 2 * 2);
   m->keep_k = keep_k;
   const size_t np = m->Npad;
   int rc = 0;
@@ -300,7 +301,7 @@ int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hi
   GemmNT g{};
   g.A = Lp + (long)(r0g - c0) * ld; g.lda = ld;
   g.B = Lp + (long)(c0g - c0) * ld; g.ldb = ld;
-  g.C = m->dK + (long)r0g * np_ + c0g; g.ldc = np_;
+  g.C = m->dK + (long)r0g * m->ldk + c0g; g.ldc = m->ldk;
   g.m = rows; g.n = ncols; g.k = w; g.sub = 1; g.lower = lower;
   // Few 128x128 tiles = a latency-bound launch on the panel chain (look-ahead block column, tail of the
   // factorisation): 64x64 tiles put 4x as many CUs on it (84 tiles at K = 256: 70 us -> 64x64: ~20 us).
@@ -319,7 +320,7 @@ int outer_update(gpk_model* m, int o, int r0g, int c0g, int ncols, int lower, hi
   GemmNT g{};
   g.A = Lo + (long)(r0g - c0) * W; g.lda = W;
   g.B = Lo + (long)(c0g - c0) * W; g.ldb = W;
-  g.C = m->dK + (long)r0g * np_ + c0g; g.ldc = np_;
+  g.C = m->dK + (long)r0g * m->ldk + c0g; g.ldc = m->ldk;
   g.m = rows; g.n = ncols; g.k = W; g.sub = 1; g.lower = lower;
   const long nc = ncols / 128, nr = rows / 128;
   const long tiles = lower ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc;
@@ -390,7 +391,7 @@ static int pair_update(gpk_model* m, int p, int r0g, hipStream_t s) {
   g.A2 = m->Lpanel(p + 1) + (long)(r0g - c1) * m->pld[p + 1]; g.lda2 = m->pld[p + 1];
   g.B2 = g.A2; g.ldb2 = g.lda2;
   g.k1 = w; g.k = w + w1;
-  g.C = m->dK + (long)r0g * np_ + r0g; g.ldc = np_;
+  g.C = m->dK + (long)r0g * m->ldk + r0g; g.ldc = m->ldk;
   g.m = rows; g.n = rows; g.sub = 1; g.lower = 1;
   return launch_gemm_auto(g, s);
 }
@@ -857,7 +858,7 @@ int build_K(gpk_model* m) {
   hipStream_t s = G.s_main;
   const int np_ = m->Npad;
   if (m->P == 1)
-    return launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, np_, m->keep_k ? 0 : 1, s);
+    return launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s);
   for (int lb = 0; lb < m->nloc; ++lb) {  // one launch per owned ownership block
     const int cg0 = (lb * m->P + m->r) * m->OB;
     int nc = m->N - cg0;
@@ -993,7 +994,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   GPK_TRY(build_K(m));
   timer_end("kbuild", s);
   if (m->keep_k)
-    GPK_HIP(hipMemcpyAsync(m->dKcopy, m->dK, (size_t)np_ * np_ * 8, hipMemcpyDeviceToDevice, s));
+    GPK_HIP(hipMemcpy2DAsync(m->dKcopy, (size_t)np_ * 8, m->dK, (size_t)m->ldk * 8, (size_t)np_ * 8, np_, hipMemcpyDeviceToDevice, s));
   if (m->k_only) {
     if (!m->keep_k) return gpk_set_err(-1, "internal: a K-only model must keep K");
     GPK_HIP(hipStreamSynchronize(s));

@@ -52,7 +52,7 @@ extern "C" int gpk_append(gpk_model** handle_inout, const double* X_new, const d
     const int rows = np_ - t0;  // tile rows to (re)compute, a multiple of 128
     // K[t0:, t0:] (lower tiles; identity on the padding) straight into the trailing block of dK
     GPK_TRY(launch_se_build(m->dX + (size_t)t0 * d, n_new - t0, rows, m->dX + (size_t)t0 * d, n_new - t0, rows, m->se, 1, 0,
-                            m->dK + (size_t)t0 * np_ + t0, np_, 1, s));
+                            m->dK + (size_t)t0 * m->ldk + t0, m->ldk, 1, s));
     if (p0 > 0) {
       Scratch sc;
       double *dR = nullptr, *dV = nullptr;
@@ -84,7 +84,7 @@ extern "C" int gpk_append(gpk_model** handle_inout, const double* X_new, const d
       // S = K[t0:, t0:] - V V^T, one lower update with K = t0
       GemmNT g{};
       g.A = dV; g.lda = np_; g.B = dV; g.ldb = np_;
-      g.C = m->dK + (size_t)t0 * np_ + t0; g.ldc = np_;
+      g.C = m->dK + (size_t)t0 * m->ldk + t0; g.ldc = m->ldk;
       g.m = rows; g.n = rows; g.k = t0; g.sub = 1; g.lower = 1;
       GPK_TRY(launch_gemm_nt(g, false, s));
       GPK_HIP(hipStreamSynchronize(s));  // dR / dV go back to the pool
