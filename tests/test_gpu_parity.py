@@ -527,6 +527,22 @@ def test_gppref_seeded_demo_matches_oracle(gpk):
     assert gp.calc_nlml(lh) == pytest.approx(-lml, rel=1e-12)
 
 
+def test_preference_demo_flow(gpk):
+    """examples/gp_preference_demo.py = GP_preference_demo.py:7-67 through dropin/GPpref, end state = the trace recorded in
+    SURVEY.md 8c (restatement-derived: parity unpinned), plus the latent posterior the demo never computes."""
+    import importlib.util
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("gp_preference_demo", os.path.join(ROOT, "examples", "gp_preference_demo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(verbose=False)
+    assert r["iters"] == 5 and r["lml"] == pytest.approx(40.5831069552, rel=1e-8)
+    np.testing.assert_allclose(r["f"][:5, 0], [-0.0761991, -1.31395028, 0.59264976, 0.47781206, 1.24381158], atol=1e-6)
+    assert r["mean"].shape == (101,) and np.all(r["var"] > -1e-9) and np.all(r["var"] <= 1.0 + 1e-9)
+    assert np.corrcoef(r["mean"], r["truth"])[0, 1] > 0.8
+
+
 @pytest.mark.parametrize("nx,d", [(300, 2), (1024, 4)])
 def test_gppref_larger_matches_oracle(gpk, nx, d):
     from gptest_amd import GPpref
