@@ -227,6 +227,8 @@ int gpk_set_option(const char* key, double value) {
     G.nb_outer = (int)value;
   } else if (k == "lookahead") {
     G.lookahead = (int)value;
+  } else if (k == "pred_gate_rows") {
+    G.pred_gate_rows = (int)value;
   } else if (k == "ldk_pad") {
     if ((int)value < 0 || (int)value > 4096 || ((int)value & 1)) return gpk_set_err(-1, "ldk_pad must be an even number in 0..4096");
     G.ldk_pad = (int)value;
@@ -284,6 +286,7 @@ double gpk_get_option(const char* key) {
   if (k == "lookahead") return G.lookahead;
   if (k == "dist_group") return G.dist_group;
   if (k == "ldk_pad") return G.ldk_pad;
+  if (k == "pred_gate_rows") return G.pred_gate_rows;
   if (k == "timing") return G.timing;
   if (k == "pool_bytes") return (double)G.pool_bytes;
   if (k == "potrf_enqueue_ms") return G.last_potrf_enqueue_ms;

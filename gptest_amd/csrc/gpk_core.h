@@ -38,6 +38,7 @@ struct Runtime {
   // inner level.  Active for Npad >= outer_from while more than outer_until columns remain; 0 = one level.
   int nb_outer = 2048, outer_from = 24576, outer_until = 8192;  // N = 16384: no gain; N = 32768: 230.6 -> 225.2 ms
   int lookahead = 1;
+  int pred_gate_rows = 0;  // experiment: substitutions start when this few columns remain (0: at once)
   int ldk_pad = 0;      // extra doubles per row of K (single GPU)
   int dist_group = 2;   // panels per ownership block of a block-cyclic (multi-GPU) model
   // tile pipeline (potrf_tail) for the chain-bound last tail_rows columns (needs 128-wide panels there: nb_small_from);

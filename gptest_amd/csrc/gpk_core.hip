@@ -1059,8 +1059,16 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   const auto host_t1 = std::chrono::steady_clock::now();
   if (pipelined) {
     if (!g_potrf_lookahead_used) return gpk_set_err(-1, "internal: pipelined substitutions without look-ahead");
-    if (!G.pipe_interleave)
+    if (!G.pipe_interleave) {
+      if (G.pred_gate_rows > 0) {
+        // experiment: hold the substitutions back until only pred_gate_rows columns remain (the chain-bound tail,
+        // where the chip has spare capacity), so that the bulk updates run alone
+        int pg = 0;
+        while (pg < m->nP && np_ - m->pc0[pg] > G.pred_gate_rows) ++pg;
+        if (pg > 0 && pg < m->nP) GPK_HIP(hipStreamWaitEvent(sq, m->ev[pg], 0));
+      }
       for (int p = 0; p < m->nP; ++p) GPK_TRY(hook(p));
+    }
     if (fuse) {
       timer_end("predict", sq);
       fused_done = true;

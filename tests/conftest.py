@@ -31,7 +31,7 @@ def golden_cases():
 # every option gpk_set_option knows, in an order that restores correctly ("nb" switches nb_auto off, so nb_auto
 # comes after it)
 OPTION_KEYS = ["nb", "nb_auto", "nb_big", "nb_big_until", "nb_small", "nb_small_from", "nb_outer", "outer_from",
-               "outer_until", "lookahead", "dist_group", "ldk_pad", "gemm_variant",
+               "outer_until", "lookahead", "dist_group", "ldk_pad", "pred_gate_rows", "gemm_variant",
                "xcd_sq", "xcd_sq_min_tiles", "tail_rows", "stamps", "pred_small_below", "small_tile_below", "leaf_algo",
                "test_gemm_k1", "pair_update", "pipe_interleave", "fuse_predict", "solve_gemm_above", "timing"]
 
