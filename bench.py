@@ -102,7 +102,7 @@ def parity_check(N, d, M, nlml, mean, var, lh):
     tests/golden/make_fullsize.py from the CPU oracle).  Returns (checked, detail, ok); ok is False on a mismatch
     beyond the north-star bar of 1e-6 relative: a fast kernel with wrong results must not print a headline
     (main() then exits with status 4 after the closing barrier, so that no other rank is left waiting)."""
-    name = {(16384, 8, 1024): "c3_16384_d8", (4096, 4, 1024): "c2_4096_d4"}.get((N, d, M))
+    name = {(16384, 8, 1024): "c3_16384_d8", (4096, 4, 1024): "c2_4096_d4", (32768, 8, 1024): "c4_32768_d8"}.get((N, d, M))
     if name is None:
         return False, "no committed fixture for N=%d d=%d M=%d" % (N, d, M), True
     g = np.load(os.path.join(ROOT, "tests", "golden", "full_%s.npz" % name))

@@ -133,6 +133,47 @@ def posterior_efficient(log_hyp, x, y, z):
     return nlml, fz, cov
 
 
+def posterior_efficient_blocked(log_hyp, x, y, z, nb=4096):
+    """posterior_efficient with the factorisation and the substitutions written over nb-wide blocks (LAPACK only ever
+    sees blocks): the flavour used for the N = 32768 fixture, where one monolithic SciPy Cholesky call crashes inside
+    OpenBLAS in this image.  Same mathematics (GPr.py:45-69); checked against posterior_efficient in
+    tests/test_oracle_golden.py."""
+    from scipy.linalg import cholesky, solve_triangular
+
+    _, sf2, _ = decode_hyp(log_hyp)
+    n = len(x)
+    A = _k_direct(log_hyp, x)                      # becomes L in place (lower blocks)
+    starts = list(range(0, n, nb))
+    for k0 in starts:
+        k1 = min(n, k0 + nb)
+        Lkk = cholesky(A[k0:k1, k0:k1], lower=True, check_finite=False)
+        A[k0:k1, k0:k1] = Lkk
+        if k1 < n:
+            A[k1:, k0:k1] = solve_triangular(Lkk, A[k1:, k0:k1].T, lower=True, check_finite=False).T
+            for j0 in starts:
+                if j0 < k1:
+                    continue
+                j1 = min(n, j0 + nb)
+                A[j0:, j0:j1] -= A[j0:, k0:k1] @ A[j0:j1, k0:k1].T
+
+    def forward(B):                                # L^-1 B, block forward substitution
+        B = np.array(B, dtype=float, copy=True)
+        for k0 in starts:
+            k1 = min(n, k0 + nb)
+            B[k0:k1] = solve_triangular(A[k0:k1, k0:k1], B[k0:k1], lower=True, check_finite=False)
+            if k1 < n:
+                B[k1:] -= A[k1:, k0:k1] @ B[k0:k1]
+        return B
+
+    w = forward(np.asarray(y, dtype=float).reshape(n))
+    logdet = float(np.sum(np.log(np.diag(A))))
+    nlml = 0.5 * float(w @ w) + logdet + n * np.log(2 * np.pi) / 2
+    V = forward(_k_direct(log_hyp, x, z))
+    fz = V.T @ w
+    cov = sf2 - np.einsum("ij,ij->j", V, V)
+    return nlml, fz, cov
+
+
 def nlml_gradient(log_hyp, x, y):
     """d nlml / d log_hyp of GPr.py:57-69 (analytic; the reference has no gradient, so this row is pinned by
     central differences of compute_likelihood_verbatim in tests/test_oracle_golden.py, not by a fixture).

@@ -1,6 +1,7 @@
-"""Full-size fixtures for BASELINE configs 2 and 3 (container-only script; ~2 min, ~6 GiB of RAM).
+"""Full-size fixtures for BASELINE configs 2, 3 (and 4's size) (container-only script; c2 + c3: ~2 min, ~6 GiB of RAM).
 
-    python tests/golden/make_fullsize.py
+    python tests/golden/make_fullsize.py            # c2 c3
+    python tests/golden/make_fullsize.py c4         # N = 32768: ~10 min, ~30 GiB
 
 Writes ``full_c3_16384_d8.npz`` (and ``full_c2_4096_d4.npz``): nlml, posterior mean and latent variance of the
 SURVEY 8(d) synthetic problem at M = 1024 test points, computed by ``oracle.gpr_oracle.posterior_efficient``
@@ -25,19 +26,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import gpr_oracle as orc  # noqa: E402
 
 
-def make(name, N, d, M):
+def make(name, N, d, M, blocked=False):
     X, y, Z, lh = orc.synthetic_problem(N, d, M)
     t0 = time.perf_counter()
-    nlml, fz, cov = orc.posterior_efficient(lh, X, y, Z)
+    nlml, fz, cov = (orc.posterior_efficient_blocked if blocked else orc.posterior_efficient)(lh, X, y, Z)
     dt = time.perf_counter() - t0
     path = os.path.join(HERE, "full_%s.npz" % name)
     np.savez(path, N=N, d=d, M=M, seed=1234, log_hyp=lh, nlml=nlml, fz=fz, cov_fz=cov,
              checksum_X=float(X.sum()), checksum_y=float(y.sum()), checksum_Z=float(Z.sum()),
-             provenance="oracle.gpr_oracle.posterior_efficient (restatement-derived; flavour pinned to the real "
-                        "GPr.py at N<=512 by test_efficient_oracle_matches_reference)")
+             provenance="oracle.gpr_oracle.posterior_efficient%s (restatement-derived; flavour pinned to the real "
+                        "GPr.py at N<=512 by test_efficient_oracle_matches_reference)" % ("_blocked" if blocked else ""))
     print("%s: nlml = %.13f  (%.1f s) -> %s" % (name, nlml, dt, path))
 
 
 if __name__ == "__main__":
-    make("c2_4096_d4", 4096, 4, 1024)
-    make("c3_16384_d8", 16384, 8, 1024)
+    which = sys.argv[1:] or ["c2", "c3"]
+    if "c2" in which:
+        make("c2_4096_d4", 4096, 4, 1024)
+    if "c3" in which:
+        make("c3_16384_d8", 16384, 8, 1024)
+    if "c4" in which:   # BASELINE config 4's size: ~10 min and ~30 GiB of RAM on 8 cores
+        make("c4_32768_d8", 32768, 8, 1024, blocked=True)   # one monolithic SciPy Cholesky of this size crashes in OpenBLAS here

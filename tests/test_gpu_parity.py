@@ -383,9 +383,9 @@ def _full_fixture(name):
     return g, X, y, Z, lh
 
 
-@pytest.mark.parametrize("name", ["c2_4096_d4", "c3_16384_d8"])
+@pytest.mark.parametrize("name", ["c2_4096_d4", "c3_16384_d8", "c4_32768_d8"])
 def test_full_size_posterior_matches_fixture(gpk, name):
-    """BASELINE configs 2 and 3 at full size, under the DEFAULT options (the 512/256/128 nb_auto panel schedule,
+    """BASELINE configs 2 and 3 (and 4's size, on one GPU: two-level blocking) at full size, under the DEFAULT options (the 512/256/128 nb_auto panel schedule,
     look-ahead, fused prediction: what bench.py and a user get), against tests/golden/full_*.npz: nlml, mean and
     latent variance from the CPU oracle's efficient flavour (restatement-derived at a size the reference cannot
     reach; that flavour is pinned to the real GPr.py at N <= 512).  Bar: 1e-6 relative (north_star)."""
@@ -809,6 +809,11 @@ def test_c4_sharded_over_8_emulated_ranks(gpk):
     assert abs(nl[0] - nl1) <= 1e-9 * abs(nl1)
     np.testing.assert_allclose(mean[0], f1, rtol=0, atol=1e-9 * np.abs(f1).max())
     np.testing.assert_allclose(var[0], c1, rtol=0, atol=1e-9)
+    g = np.load(os.path.join(GOLDEN, "full_c4_32768_d8.npz"))   # CPU oracle at this size (tests/golden/make_fullsize.py c4)
+    assert float(g["checksum_X"]) == float(X.sum()) and float(g["checksum_Z"]) == float(Z.sum())
+    assert abs(nl[0] - float(g["nlml"])) <= RTOL * abs(float(g["nlml"]))
+    np.testing.assert_allclose(mean[0], g["fz"], rtol=0, atol=RTOL * np.abs(g["fz"]).max())
+    np.testing.assert_allclose(var[0], g["cov_fz"], rtol=0, atol=RTOL * np.exp(lh[-2]) ** 2)
     sf2 = np.exp(lh[-2]) ** 2
     assert np.all(var[0] > -1e-9) and np.all(var[0] <= sf2 + 1e-12)
 

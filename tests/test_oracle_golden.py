@@ -90,3 +90,24 @@ def test_oracle_gradient_matches_central_differences(N, d, seed):
         fd = (orc.compute_likelihood_verbatim(lh + e, x, y).flat[0]
               - orc.compute_likelihood_verbatim(lh - e, x, y).flat[0]) / (2 * h)
         assert abs(g[k] - fd) <= 1e-6 * max(1.0, abs(fd))
+
+
+def test_blocked_efficient_flavour_matches_the_monolithic_one():
+    """posterior_efficient_blocked (used for the N = 32768 fixture, where one monolithic SciPy Cholesky crashes inside
+    OpenBLAS in this image) against posterior_efficient on a ragged block split, and against the committed C2 fixture."""
+    import os
+
+    from conftest import GOLDEN
+
+    X, y, Z, lh = orc.synthetic_problem(1300, 3, 40)
+    a = orc.posterior_efficient(lh, X, y, Z)
+    b = orc.posterior_efficient_blocked(lh, X, y, Z, nb=300)
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0])
+    np.testing.assert_allclose(b[1], a[1], rtol=0, atol=1e-11 * np.abs(a[1]).max())
+    np.testing.assert_allclose(b[2], a[2], rtol=0, atol=1e-12)
+    g = np.load(os.path.join(GOLDEN, "full_c2_4096_d4.npz"))
+    X, y, Z, lh = orc.synthetic_problem(4096, 4, 1024)
+    c = orc.posterior_efficient_blocked(lh, X, y, Z, nb=1024)
+    assert abs(c[0] - float(g["nlml"])) <= 1e-12 * abs(float(g["nlml"]))
+    np.testing.assert_allclose(c[1], g["fz"], rtol=0, atol=1e-10 * np.abs(g["fz"]).max())
+    np.testing.assert_allclose(c[2], g["cov_fz"], rtol=0, atol=1e-11)
