@@ -3,6 +3,7 @@
 #include "../../include/gpk.h"
 #include "gpk_core.h"
 #include <cmath>
+#include <map>
 
 const char* gpk_err_cstr();
 
@@ -40,8 +41,9 @@ int gpk_init(int device) {
   // workgroup resident; behind a queue of thousands of 72 KiB GEMM workgroups it would starve.
   // So one CU is reserved (CU mask) for the leaf stream and the GEMM streams get the other 255.
   const int ncu = prop.multiProcessorCount;
-  const char* env_res = getenv("GPK_RESERVE_CU");
+  const char* env_res = getenv("GPK_RESERVE_CU");  // 0: nothing masked (then option leaf_server defaults to 1)
   const bool want_reserve = !(env_res && env_res[0] == '0') && ncu >= 64;
+  G.leaf_server = want_reserve ? 0 : 1;
   bool masked = false;
   if (want_reserve) {
     const int words = (ncu + 31) / 32;
@@ -116,9 +118,14 @@ int gpk_init(int device) {
   int lo = 0, hi = 0;
   GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
   if (!masked) {
-    GPK_HIP(hipStreamCreateWithPriority(&G.s_main, hipStreamNonBlocking, lo));
+    // Nothing masked: the update stream at normal priority, the panel chain and the substitutions above it, and the
+    // leaf on its resident server (LeafSession; the server's stream is created with the first session).
+    const char* env_mp = getenv("GPK_MAIN_PRIO");  // 3: low priority for the update stream
+    GPK_HIP(hipStreamCreateWithPriority(&G.s_main, hipStreamNonBlocking, (env_mp && env_mp[0] == '3') ? lo : (lo + hi) / 2));
     GPK_HIP(hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, hi));
-    GPK_HIP(hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, lo));
+    const char* env_qp = getenv("GPK_PRED_PRIO");
+    GPK_HIP(hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking,
+                                        (env_qp && env_qp[0] == '3') ? lo : (env_qp && env_qp[0] == '2') ? (lo + hi) / 2 : hi));
   }
   G.cu_reserved = masked;
   G.ncu = masked ? ncu - G.ncu_reserved : ncu;
@@ -179,6 +186,11 @@ void gpk_shutdown(void) {
     g_parked_device = G.device;
     g_parked_reserved = G.ncu_reserved;
   }
+  SD_STEP("destroy s_leaf", if (G.s_leaf) (void)hipStreamDestroy(G.s_leaf));
+  G.s_leaf = nullptr;
+  G.leaf_chain = nullptr;
+  if (G.leaf_mb) (void)hipFree(G.leaf_mb);
+  G.leaf_mb = nullptr;
   SD_STEP("destroy s_rows", if (G.s_rows) (void)hipStreamDestroy(G.s_rows));
   SD_STEP("destroy s_comm", if (G.s_comm) (void)hipStreamDestroy(G.s_comm));
   G.s_comm = nullptr;
@@ -266,6 +278,8 @@ int gpk_set_option(const char* key, double value) {
     G.test_gemm_k1 = (int)value;
   } else if (k == "pair_update") {
     G.pair_update = (int)value;
+  } else if (k == "leaf_server") {
+    G.leaf_server = (int)value ? 1 : 0;
   } else if (k == "pipe_interleave") {
     G.pipe_interleave = (int)value;
   } else if (k == "fuse_predict") {
@@ -307,6 +321,8 @@ double gpk_get_option(const char* key) {
   if (k == "pred_small_below") return G.pred_small_below;
   if (k == "small_tile_below") return G.small_tile_below;
   if (k == "pair_update") return G.pair_update;
+  if (k == "leaf_server") return G.leaf_server;
+  if (k == "cu_reserved") return G.cu_reserved ? G.ncu_reserved : 0;
   if (k == "pipe_interleave") return G.pipe_interleave;
   if (k == "fuse_predict") return G.fuse_predict;
   if (k == "solve_gemm_above") return G.solve_gemm_above;
@@ -413,6 +429,7 @@ int gpk_potrf(double* A, int N) {
     int hinfo = 0;
     if (hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
     if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "potrf: %s", hipGetErrorString(hipGetLastError())); break; }
+    if (hinfo >= LEAF_SERVER_INFO_POISON) { rc = gpk_set_err(-3, "gpk_potrf: the resident leaf server did not answer (mailbox time-out)"); break; }
     if (hinfo > 0) { rc = hinfo > N ? N : hinfo; gpk_set_err(rc, "matrix is not positive definite (leading minor %d)", rc); break; }
     rc = model_unpack_L(m, A);
   } while (0);
@@ -1012,6 +1029,113 @@ int gpk_bench_mfma_peak2(int nacc, int waves_per_simd, int iters, double* tflops
 
 int gpk_bench_mfma_peak(int iters, double* tflops_out) { return gpk_bench_mfma_peak2(8, 2, iters, tflops_out); }
 
+}  // extern "C"
+
+// The same issue loop with the residency PINNED: a workgroup of 4 waves (one per SIMD) owns 160 KiB / W of LDS, so a CU
+// holds exactly W of them and a grid of 256 * W workgroups puts W waves on every SIMD.  (gpk_bench_mfma_peak2 leaves the
+// placement to the dispatcher, which stacks W + 1 workgroups on some CUs: its n/(n+1) "ceiling" is load imbalance.)
+template <int W, int NACC, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void mfma_pinned_kernel(double* out, unsigned* where, int iters, double seed) {
+  __shared__ double pin[(160 * 1024 / W) * (THREADS / 256) / 8];
+  if (iters < 0) pin[threadIdx.x] = seed;  // never taken: keeps the allocation
+  d4_t acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (d4_t){0, 0, 0, 0};
+  double a = seed + threadIdx.x * 1e-3 * seed, b = seed - threadIdx.x * 1e-3 * seed;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // XCC_ID
+    unsigned* w4 = where + ((size_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)) * 4;
+    w4[0] = hw;
+    w4[1] = xcc;
+    w4[2] = (unsigned)(c1 - c0);
+    w4[3] = (unsigned)(r1 - r0);
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" {
+
+// out[0] TFLOP/s (event-timed), out[1] shader GHz (mean over waves), out[2] / out[3] max / min waves on an occupied SIMD,
+// out[4] SIMDs occupied, out[5] TFLOP/s from the slowest wave's own cycle count (launch ramp excluded).
+int gpk_bench_mfma_pinned(int waves_per_simd, int iters, double* out) {
+  GPK_TRY(rt_require());
+  if (iters <= 0) return gpk_set_err(-1, "gpk_bench_mfma_pinned: iters must be positive");
+  const int W = waves_per_simd;
+  if (W != 1 && W != 2 && W != 4 && W != 8) return gpk_set_err(-1, "gpk_bench_mfma_pinned: waves_per_simd must be 1, 2, 4 or 8");
+  hipStream_t s = (G.s_pred && !getenv("GPK_BENCH_MASKED")) ? G.s_pred : G.s_main;  // s_pred is unmasked: all 256 CUs
+  const int threads = getenv("GPK_BENCH_THREADS") ? atoi(getenv("GPK_BENCH_THREADS")) : 256;
+  if (threads != 256 && !(W == 4 && (threads == 512 || threads == 1024)))
+    return gpk_set_err(-1, "gpk_bench_mfma_pinned: 512 / 1024 threads only with 4 waves per SIMD");
+  const int blocks = (getenv("GPK_BENCH_CUS") ? atoi(getenv("GPK_BENCH_CUS")) : 256) * W * 256 / threads;
+  Scratch sc;
+  double* d = nullptr;
+  unsigned* where = nullptr;
+  GPK_TRY(sc.get(&d, (size_t)blocks * threads));
+  GPK_TRY(sc.get(&where, (size_t)blocks * (threads / 64) * 4));
+  hipEvent_t e0, e1;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  auto go = [&](int n) {
+    switch (W) {
+      case 1: hipLaunchKernelGGL((mfma_pinned_kernel<1, 4>), dim3(blocks), dim3(256), 0, s, d, where, n, 0.5); break;
+      case 2: hipLaunchKernelGGL((mfma_pinned_kernel<2, 4>), dim3(blocks), dim3(256), 0, s, d, where, n, 0.5); break;
+      case 4:
+        if (threads == 512) hipLaunchKernelGGL((mfma_pinned_kernel<4, 4, 512>), dim3(blocks), dim3(512), 0, s, d, where, n, 0.5);
+        else if (threads == 1024) hipLaunchKernelGGL((mfma_pinned_kernel<4, 4, 1024>), dim3(blocks), dim3(1024), 0, s, d, where, n, 0.5);
+        else hipLaunchKernelGGL((mfma_pinned_kernel<4, 4>), dim3(blocks), dim3(256), 0, s, d, where, n, 0.5);
+        break;
+      default: hipLaunchKernelGGL((mfma_pinned_kernel<8, 4>), dim3(blocks), dim3(256), 0, s, d, where, n, 0.5); break;
+    }
+  };
+  go(iters / 10 + 1);
+  GPK_HIP(hipEventRecord(e0, s));
+  go(iters);
+  GPK_HIP(hipEventRecord(e1, s));
+  GPK_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const int nwaves = blocks * (threads / 64);
+  std::vector<unsigned> h((size_t)nwaves * 4);
+  GPK_HIP(hipMemcpy(h.data(), where, h.size() * 4, hipMemcpyDeviceToHost));
+  std::map<unsigned long long, int> per_simd;
+  double ghz = 0, max_cyc = 0;
+  for (int i = 0; i < nwaves; ++i) {
+    const unsigned hw = h[(size_t)i * 4], xcc = h[(size_t)i * 4 + 1];
+    // HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]
+    const unsigned long long key = ((unsigned long long)xcc << 32) | (hw & 0xff30u);
+    per_simd[key]++;
+    ghz += (double)h[(size_t)i * 4 + 2] / (double)h[(size_t)i * 4 + 3] * 0.1;
+    max_cyc = std::max(max_cyc, (double)h[(size_t)i * 4 + 2]);
+  }
+  ghz /= nwaves;
+  int mx = 0, mn = 1 << 30;
+  for (auto& kv : per_simd) {
+    mx = std::max(mx, kv.second);
+    mn = std::min(mn, kv.second);
+  }
+  const double flops = (double)nwaves * (double)iters * 4 * 2048.0;
+  out[0] = flops / (ms * 1e-3) / 1e12;
+  out[1] = ghz;
+  out[2] = mx;
+  out[3] = mn;
+  out[4] = (double)per_simd.size();
+  out[5] = flops / (max_cyc / (ghz * 1e9)) / 1e12;
+  return 0;
+}
+
 int gpk_bench_leaf(int dbg_skip, int reps, double* us_out) {
   GPK_TRY(rt_require());
   hipStream_t s = G.s_main;
@@ -1215,7 +1339,7 @@ int gpk_bench_chain_step(int reps, int nsmall, int small_m, double* us_alone, do
   auto run_chain = [&](double* out) -> int {
     GPK_HIP(hipEventRecord(e0, sl));
     for (int r = 0; r < reps; ++r) {
-      GPK_TRY(launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, 0, sl));
+      GPK_TRY(leaf_launch(dA, 128, dL, 128, dD, dinfo, 0, sl));
       for (int q = 0; q < nsmall; ++q) {
         GemmNT g{};
         g.A = gA; g.lda = gk; g.B = dD; g.ldb = 128; g.C = tC; g.ldc = 128;
@@ -1230,12 +1354,15 @@ int gpk_bench_chain_step(int reps, int nsmall, int small_m, double* us_alone, do
     *out = 1e3 * ms / reps;
     return 0;
   };
-  GPK_TRY(run_chain(us_alone));
-  GemmNT g{};
-  g.A = gA; g.lda = gk; g.B = gA; g.ldb = gk; g.C = gC; g.ldc = gm; g.m = gm; g.n = gm; g.k = gk; g.sub = 1; g.lower = 1;
-  const int nbig = (int)(reps * 0.12) + 20;  // ~0.37 ms each: enough to outlast the chain
-  for (int r = 0; r < nbig; ++r) GPK_TRY(launch_gemm_nt(g, true, sm));
-  GPK_TRY(run_chain(us_contended));
+  {
+    LeafSession leaf_session(sl);  // (no device-wide synchronisation while it is open: the server only leaves on its quit message)
+    GPK_TRY(run_chain(us_alone));
+    GemmNT g{};
+    g.A = gA; g.lda = gk; g.B = gA; g.ldb = gk; g.C = gC; g.ldc = gm; g.m = gm; g.n = gm; g.k = gk; g.sub = 1; g.lower = 1;
+    const int nbig = (int)(reps * 0.12) + 20;  // ~0.37 ms each: enough to outlast the chain
+    for (int r = 0; r < nbig; ++r) GPK_TRY(launch_gemm_nt(g, true, sm));
+    GPK_TRY(run_chain(us_contended));
+  }
   GPK_HIP(hipDeviceSynchronize());
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -1279,7 +1406,7 @@ int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_o
 
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out) {
   GPK_TRY(rt_require());
-  hipStream_t s = G.s_main;
+  hipStream_t s = (getenv("GPK_BENCH_UNMASKED") && G.s_pred) ? G.s_pred : G.s_main;
   double *dA = nullptr, *dB = nullptr, *dC = nullptr;
   GPK_TRY(dev_alloc_t(&dA, (size_t)m * k));
   GPK_TRY(dev_alloc_t(&dC, (size_t)m * n));

@@ -25,6 +25,13 @@ struct Runtime {
   hipStream_t s_rows = nullptr;   // tile pipeline of the chain-bound tail: the full-height panel GEMMs (s_panel keeps the leaves)
   bool cu_reserved = false;
   int ncu_reserved = 8;
+  // resident leaf server (gpk_internal.h: LeafMailbox): its stream, its mailbox, the next sequence number, and the
+  // chain stream of the open session (nullptr: none open, leaves are launched directly)
+  hipStream_t s_leaf = nullptr;
+  LeafMailbox* leaf_mb = nullptr;
+  unsigned leaf_seq = 1;
+  hipStream_t leaf_chain = nullptr;
+  int leaf_server = 1;  // option: 0 = always launch the leaf kernel directly
   std::map<size_t, std::vector<void*>> pool;
   size_t pool_bytes = 0;
   // options
@@ -73,6 +80,18 @@ int rt_require();
 int dev_alloc(void** p, size_t bytes);
 void dev_free(void* p, size_t bytes);
 template <class T> int dev_alloc_t(T** p, size_t n) { return dev_alloc((void**)p, n * sizeof(T)); }
+
+// One factorisation's lease on the leaf server: the server is launched when the session opens, leaf_launch() on the
+// session's chain stream posts tiles to it, and the destructor queues the quit message on that stream -- whichever way
+// the factorisation's host code ends, the server is told to leave.  Nested sessions are no-ops.
+struct LeafSession {
+  bool owner = false;
+  explicit LeafSession(hipStream_t chain);
+  ~LeafSession();
+  LeafSession(const LeafSession&) = delete;
+  LeafSession& operator=(const LeafSession&) = delete;
+};
+int leaf_launch(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, hipStream_t s);
 
 // Scratch device buffers of one API call: returned to the pool when the call ends, whichever way it ends (the update
 // stream is drained first, so nothing queued can still touch them).

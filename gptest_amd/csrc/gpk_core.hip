@@ -256,6 +256,40 @@ int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m) {
 // sub-panels inside a panel.  L goes to its own panel-packed storage (panel p =
 // rows c0.. x w, ld = w): compact operands for every later kernel and no in-place hazard
 // in the panel solve.  Replaces np.linalg.cholesky (GPr.py:62, GPpref.py:128).
+LeafSession::LeafSession(hipStream_t chain) {
+  if (!G.leaf_server || G.leaf_chain || !chain) return;
+  if (!G.s_leaf && hipStreamCreateWithFlags(&G.s_leaf, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    G.s_leaf = nullptr;
+    return;
+  }
+  if (!G.leaf_mb) {
+    if (hipMalloc((void**)&G.leaf_mb, sizeof(LeafMailbox)) != hipSuccess || hipMemset(G.leaf_mb, 0, sizeof(LeafMailbox)) != hipSuccess) {
+      (void)hipGetLastError();
+      G.leaf_mb = nullptr;
+      return;
+    }
+    G.leaf_seq = 1;
+  }
+  if (hipMemsetAsync(&G.leaf_mb->err, 0, 4, G.s_leaf) != hipSuccess) return;
+  if (launch_leaf_server(G.leaf_mb, G.leaf_seq, G.s_leaf) != 0) return;
+  G.leaf_chain = chain;
+  owner = true;
+}
+
+LeafSession::~LeafSession() {
+  if (!owner) return;
+  // the quit message travels down the chain stream behind the last tile; if even that cannot be queued the server
+  // leaves by itself after LEAF_SERVER_LIMIT_TICKS without a message
+  (void)launch_leaf_proxy(G.leaf_mb, G.leaf_seq++, 1, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, G.leaf_chain);
+  G.leaf_chain = nullptr;
+}
+
+int leaf_launch(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, hipStream_t s) {
+  if (G.leaf_chain && s == G.leaf_chain) return launch_leaf_proxy(G.leaf_mb, G.leaf_seq++, 0, A, lda, L, ldl, Dinv, info, col0, s);
+  return launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, s);
+}
+
 int factor_panel(gpk_model* m, int p, hipStream_t s) {
   const int c0 = m->pc0[p], w = m->pw[p], np_ = m->Npad;
   const long ldk = m->ldk, ld = m->pld[p];
@@ -276,7 +310,7 @@ int factor_panel(gpk_model* m, int p, hipStream_t s) {
       GPK_TRY(launch_gemm_nt(g, false, s));
     }
     double* Dt = m->dDinv + (long)(cs / 128) * 128 * 128;
-    GPK_TRY(launch_potf2_trtri_128(Acol, ldk, Lp + (long)ro * ld + sb * 128, ld, Dt, m->dinfo, cs, 0, s));
+    GPK_TRY(leaf_launch(Acol, ldk, Lp + (long)ro * ld + sb * 128, ld, Dt, m->dinfo, cs, s));
     if (h - ro - 128 > 0) {
       // L[cs+128:, sub-panel] = A[cs+128:, cs:cs+128] * Dinv^T
       GemmNT g{};
@@ -498,7 +532,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
     double* Dt = m->dDinv + (long)(c0 / 128) * 128 * 128;
     hipEvent_t rest_before = (p > p_first) ? ev_rest[p - 1] : ev_prev_rest;
     // ---- critical stream
-    GPK_TRY(launch_potf2_trtri_128(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, 0, sc));
+    GPK_TRY(leaf_launch(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, sc));
     GPK_HIP(hipEventRecord(ev_leaf[p], sc));
     if (h > 128) {
       if (p > p_first) GPK_HIP(hipStreamWaitEvent(sc, ev_near[p - 1], 0));
@@ -606,6 +640,7 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   // run faster (50 vs 44.5 TFLOP/s) but the three narrow updates per pair it needs (16 % of the flops) cost more
   // than that (N = 16384: 38.1-38.5 vs 36.9-37.05 ms, N = 32768: 241.8 vs 231.9).  1: only up to 8192, 2: always.
   g_potrf_tail_from = -1;
+  LeafSession leaf_session(sp);  // the panel chain's leaves go to the resident server from here on
   if (nP >= 6 && m->nO == nP && tail_first_panel(m) == m->nO && (G.pair_update == 2 || (G.pair_update == 1 && m->Npad <= 8192)))
     return potrf_device_paired(m, after_panel);
   GPK_TRY(model_events(m, 7 * nP + 8));
@@ -1108,6 +1143,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   if (G.stamps && G.dstamps) GPK_HIP(hipMemcpyAsync(G.hstamps.data(), G.dstamps, 1024 * 8, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipStreamSynchronize(s));
   m->info = hinfo;
+  if (hinfo >= LEAF_SERVER_INFO_POISON) return gpk_set_err(-3, "fit: the resident leaf server did not answer (mailbox time-out)");
   if (hinfo > 0) return hinfo > m->N ? m->N : hinfo;
   m->factored = true;
   m->logdet = hs[0];

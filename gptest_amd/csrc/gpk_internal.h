@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +62,32 @@ int launch_gemm_auto(const GemmNT& g, hipStream_t s);
 // (col0 + j + 1) of the first non-positive pivot (only if it is still 0).
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info,
                            int col0, int n_valid, hipStream_t s);
+
+// The resident leaf server.  One 1024-thread workgroup (the leaf's own shape: a whole CU) is launched once per
+// factorisation on a stream of its own and stays on its CU; the panel chain reaches it through a mailbox in HBM: a
+// one-wave PROXY kernel in the chain stream posts the tile and spins until the server reports it done, so stream order
+// and every dependency of the chain stay what they are with a direct launch.  What it buys: the leaf needs an EMPTY
+// CU (132 KiB of LDS), which beside thousands of queued GEMM workgroups only a CU mask on the update stream could
+// guarantee -- and a CU-masked queue places its waves unevenly over the SIMDs (scripts/mfma_pinned.py: 5/3 and 6/2
+// waves per SIMD instead of 4/4), which costs the bulk update ~10 %.  With the server nothing is masked.
+// Every wait is bounded (LEAF_SERVER_LIMIT_TICKS of the 100 MHz clock): a server that hears nothing exits, a proxy
+// whose server does not answer gives up, both raise `err`, and the proxy poisons *info (LEAF_SERVER_INFO_POISON).
+struct LeafMailbox {
+  const double* A; long lda;
+  double* L; long ldl;
+  double* Dinv;
+  int* info;
+  int col0, op;              // op 0: factor a tile, 1: quit
+  unsigned pad0[18];
+  unsigned go;  unsigned pad1[31];    // sequence number of the posted task (own 128-byte line)
+  unsigned done; unsigned pad2[31];   // sequence number of the last finished task
+  unsigned err;  unsigned pad3[31];   // 1: the server timed out, 2: a proxy timed out
+};
+constexpr unsigned long long LEAF_SERVER_LIMIT_TICKS = 500000000ull;  // 5 s
+constexpr int LEAF_SERVER_INFO_POISON = 0x40000000;
+int launch_leaf_server(LeafMailbox* mb, unsigned first_seq, hipStream_t s);
+int launch_leaf_proxy(LeafMailbox* mb, unsigned seq, int op, const double* A, long lda, double* L, long ldl,
+                      double* Dinv, int* info, int col0, hipStream_t s);
 
 // ---------------------------------------------------------------- builders
 struct SEParams {

@@ -159,7 +159,7 @@ int g_gemm_variant = 8;  // 8: 8-wave 128x128 kernel (default); 4: the 4-wave ke
 // sub mode: the accumulators START as C (loaded while the first K-slab is in flight) and A is
 // negated on its way into LDS, so the MFMA chain itself yields C - A*B^T and the epilogue is
 // store-only (no load -> subtract -> store dependency at the end of every tile).
-template <bool TWOSEG>  // TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update)
+template <bool TWOSEG, int DBG = 0>  // TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update)
 __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   constexpr int BT = 128;
   __shared__ double lds[2 * 2 * BT * LDS_LD];
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   const unsigned c_off = (unsigned)fg * (unsigned)g.ldc + (unsigned)fr;
 
   d4 acc[4][2];
-  if (g.sub) {
+  if (g.sub && !(DBG & 8)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -290,25 +290,43 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   gload(0);
   lstore(0);
   __syncthreads();
+  double fa[4], fb[2];
+  if (DBG & 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = As[(wm * 64 + fr + i * 16) * LDS_LD + fg];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = Bs[(wn * 32 + fr + j * 16) * LDS_LD + fg];
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    if (!(DBG & 1) && kt + 1 < nk) gload(kt + 1);
     const double* Ab = As + (buf * BT + wm * 64 + fr) * LDS_LD + fg;
     const double* Bb = Bs + (buf * BT + wn * 32 + fr) * LDS_LD + fg;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
       double a[4], b[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = Ab[i * 16 * LDS_LD + kk];
+      for (int i = 0; i < 4; ++i) a[i] = (DBG & 4) ? fa[i] : Ab[i * 16 * LDS_LD + kk];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bb[j * 16 * LDS_LD + kk];
+      for (int j = 0; j < 2; ++j) b[j] = (DBG & 4) ? fb[j] : Bb[j * 16 * LDS_LD + kk];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
-    __syncthreads();
+    if (!(DBG & 1) && kt + 1 < nk) lstore(buf ^ 1);
+    if (!(DBG & 2)) __syncthreads();
+  }
+  if (DBG & 8) {
+    double t = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t += acc[i][j][r];
+    if (t == 12345.678) Cw[c_off] = t;
+    return;
   }
   // Write-through (sc1) stores: the C tiles are not re-read before the next panel step, and lines left dirty in
   // the XCD L2s make EVERY kernel boundary on the chip pay for their write-back (the end-of-kernel release of the
@@ -350,7 +368,16 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
       const long nsq = g.lower ? SN * (SN + 1) / 2 + (SM - SN) * SN : SM * SN;
       nblk = ((nsq + 7) / 8) * 8 * 64;
     }
+    static const int dbg = getenv("GPK_GEMM_DBG") ? atoi(getenv("GPK_GEMM_DBG")) : 0;
     if (g.k1 > 0) hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, g);
+    else if (dbg == 1) hipLaunchKernelGGL((gemm_nt8_kernel<false, 1>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+    else if (dbg == 2) hipLaunchKernelGGL((gemm_nt8_kernel<false, 2>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+    else if (dbg == 3) hipLaunchKernelGGL((gemm_nt8_kernel<false, 3>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+    else if (dbg == 4) hipLaunchKernelGGL((gemm_nt8_kernel<false, 4>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+    else if (dbg == 5) hipLaunchKernelGGL((gemm_nt8_kernel<false, 5>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+    else if (dbg == 7) hipLaunchKernelGGL((gemm_nt8_kernel<false, 7>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+    else if (dbg == 8) hipLaunchKernelGGL((gemm_nt8_kernel<false, 8>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+    else if (dbg == 15) hipLaunchKernelGGL((gemm_nt8_kernel<false, 15>), dim3((unsigned)nblk), dim3(512), 0, s, g);
     else hipLaunchKernelGGL(gemm_nt8_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, s, g);
   }
   else if (tile128)

@@ -102,23 +102,29 @@ static __device__ __forceinline__ void leaf_update_tile(double* S, int c0, int t
   for (int r = 0; r < 4; ++r) S[(RI + fg + 4 * r) * PLD + RJ + fr] = acc[r];
 }
 
-template <int ALGO>  // 0: column-by-column elimination in registers; 1: blocked elimination (default)
-__global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __restrict__ A, long lda,
-                                                               double* __restrict__ L, long ldl,
-                                                               double* __restrict__ Dinv, int* info, int col0,
-                                                               int dbg_skip) {
+// The leaf's work on one tile.  S (128 * PLD + 2 * CBLD + 128 doubles, 16-byte aligned), rinvb (16) and failflag live
+// in the calling kernel's LDS: the one-shot kernel below and the resident leaf server share this body.
+// COH: the tile is read and the results are written THROUGH the caches (agent-scope accesses): the resident server
+// neither invalidates nor writes back its XCD's L2 per tile, which the other kernels on that XCD would pay for.
+template <bool COH> static __device__ __forceinline__ double leaf_ldg(const double* p) {
+  return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool COH> static __device__ __forceinline__ void leaf_stg(double* p, double v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <int ALGO, bool COH = false>  // 0: column-by-column elimination in registers; 1: blocked elimination (default)
+static __device__ __forceinline__ void leaf_body(const double* __restrict__ A, long lda, double* __restrict__ L, long ldl,
+                                                 double* __restrict__ Dinv, int* info, int col0, int dbg_skip,
+                                                 double* S, double* rinvb, int& failflag, const int tid) {
   constexpr int algo = ALGO;
-  __shared__ __attribute__((aligned(16))) double S[128 * PLD + 2 * CBLD + 128];
-  __shared__ double rinvb[16];
-  __shared__ int failflag;
   double* colbuf = S + 128 * PLD;       // [2][CBLD]; 128*129 and CBLD are even -> 16-byte aligned pair reads
   double* pivbuf = colbuf + 2 * CBLD;   // [128] pivots
-  const int tid = threadIdx.x;
 #define LEAF_STAMP(k) do { if ((dbg_skip & 8) && tid == 0) info[k] = (int)__builtin_amdgcn_s_memrealtime(); } while (0)
   LEAF_STAMP(3);
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int i = e >> 7, j = e & 127;
-    S[i * PLD + j] = A[(long)i * lda + j];
+    S[i * PLD + j] = leaf_ldg<COH>(A + (long)i * lda + j);
   }
   __syncthreads();
   LEAF_STAMP(4);
@@ -196,8 +202,8 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
     for (int e = tid; e < 128 * 128; e += 1024) {
       const int ii = e >> 7, jj = e & 127;
       const double v = (ii == jj) ? 1.0 : 0.0;
-      L[(long)ii * ldl + jj] = v;
-      Dinv[ii * 128 + jj] = v;
+      leaf_stg<COH>(L + (long)ii * ldl + jj, v);
+      leaf_stg<COH>(Dinv + ii * 128 + jj, v);
     }
     return;
   }
@@ -274,8 +280,8 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
       for (int e = tid; e < 128 * 128; e += 1024) {
         const int ii = e >> 7, jj = e & 127;
         const double v = (ii == jj) ? 1.0 : 0.0;
-        L[(long)ii * ldl + jj] = v;
-        Dinv[ii * 128 + jj] = v;
+        leaf_stg<COH>(L + (long)ii * ldl + jj, v);
+        leaf_stg<COH>(Dinv + ii * 128 + jj, v);
       }
       return;
     }
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   }
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int ii = e >> 7, jj = e & 127;
-    L[(long)ii * ldl + jj] = S[ii * PLD + jj];
+    leaf_stg<COH>(L + (long)ii * ldl + jj, S[ii * PLD + jj]);
   }
   __syncthreads();
   if (tid < 128) S[tid * PLD + tid] = 1.0 / S[tid * PLD + tid];
@@ -366,9 +372,20 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   LEAF_STAMP(6);
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int ii = e >> 7, jj = e & 127;
-    Dinv[e] = (jj <= ii) ? S[ii * PLD + jj] : 0.0;
+    leaf_stg<COH>(Dinv + e, (jj <= ii) ? S[ii * PLD + jj] : 0.0);
   }
   LEAF_STAMP(7);
+}
+
+template <int ALGO>
+__global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __restrict__ A, long lda,
+                                                               double* __restrict__ L, long ldl,
+                                                               double* __restrict__ Dinv, int* info, int col0,
+                                                               int dbg_skip) {
+  __shared__ __attribute__((aligned(16))) double S[128 * PLD + 2 * CBLD + 128];
+  __shared__ double rinvb[16];
+  __shared__ int failflag;
+  leaf_body<ALGO>(A, lda, L, ldl, Dinv, info, col0, dbg_skip, S, rinvb, failflag, (int)threadIdx.x);
 }
 
 int g_leaf_algo = 1;  // 1: blocked elimination (16-column steps, MFMA updates); 0: column-by-column in registers
@@ -378,6 +395,124 @@ int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, doubl
     hipLaunchKernelGGL(potf2_trtri_128_kernel<0>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
   else
     hipLaunchKernelGGL(potf2_trtri_128_kernel<1>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- resident leaf server (see gpk_internal.h)
+static __device__ __forceinline__ unsigned mb_load(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void mb_store(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int ALGO>
+__global__ __launch_bounds__(1024) void leaf_server_kernel(LeafMailbox* mb, unsigned first_seq) {
+  __shared__ __attribute__((aligned(16))) double S[128 * PLD + 2 * CBLD + 128];
+  __shared__ double rinvb[16];
+  __shared__ int failflag;
+  __shared__ unsigned long long t_ptr[5];
+  __shared__ long t_ld[2];
+  __shared__ int t_int[3];  // col0, command (0 tile, 1 quit, 2 timed out)
+  const int tid = threadIdx.x;
+  for (unsigned seq = first_seq;; ++seq) {
+    if (tid == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      int cmd = 0;
+      while (mb_load(&mb->go) != seq) {
+        __builtin_amdgcn_s_sleep(4);
+        if (mb_load(&mb->err) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > LEAF_SERVER_LIMIT_TICKS) {
+          cmd = 2;
+          break;
+        }
+      }
+      if (cmd == 0) {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(mb);
+        t_ptr[0] = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // A
+        t_ld[0] = (long)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t_ptr[1] = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L
+        t_ld[1] = (long)__hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t_ptr[2] = __hip_atomic_load(q + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // Dinv
+        t_ptr[3] = __hip_atomic_load(q + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // info
+        const unsigned long long co = __hip_atomic_load(q + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t_int[0] = (int)(unsigned)(co & 0xffffffffull);
+        cmd = (int)(unsigned)(co >> 32) ? 1 : 0;
+      }
+      t_int[1] = cmd;
+    }
+    __syncthreads();
+    const int cmd = t_int[1];
+    if (cmd == 2) {
+      if (tid == 0) mb_store(&mb->err, 1u);
+      return;
+    }
+    if (cmd == 1) {
+      if (tid == 0) mb_store(&mb->done, seq);
+      return;
+    }
+    // The tile was written by an earlier kernel of the chain (complete and written back before the proxy ran) and is
+    // read past the caches; L and Dinv are written through them: no invalidate, no write-back of this XCD's L2.
+    auto uni = [](unsigned long long v) -> unsigned long long {  // workgroup-uniform: keep it in scalar registers
+      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffull));
+      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+      return ((unsigned long long)hi << 32) | lo;
+    };
+    const double* tA = reinterpret_cast<const double*>(uni(t_ptr[0]));
+    double* tL = reinterpret_cast<double*>(uni(t_ptr[1]));
+    double* tD = reinterpret_cast<double*>(uni(t_ptr[2]));
+    int* tinfo = reinterpret_cast<int*>(uni(t_ptr[3]));
+    const long tlda = (long)uni((unsigned long long)t_ld[0]), tldl = (long)uni((unsigned long long)t_ld[1]);
+    const int tcol0 = __builtin_amdgcn_readfirstlane(t_int[0]);
+    int tid_it = tid;  // a fresh value per tile: the body's index arithmetic is NOT hoisted out of the server loop
+    asm volatile("" : "+v"(tid_it));  // (hoisted, it stays live across the whole body: 11 spilled registers)
+    leaf_body<ALGO, true>(tA, tlda, tL, tldl, tD, tinfo, tcol0, 0, S, rinvb, failflag, tid_it);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left before the barrier
+    __syncthreads();
+    if (tid == 0) mb_store(&mb->done, seq);
+  }
+}
+
+__global__ __launch_bounds__(64) void leaf_proxy_kernel(LeafMailbox* mb, unsigned seq, int op, const double* A, long lda,
+                                                        double* L, long ldl, double* Dinv, int* info, int col0) {
+  if (threadIdx.x != 0) return;
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(mb);
+  __hip_atomic_store(q + 0, (unsigned long long)A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, (unsigned long long)lda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 2, (unsigned long long)L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 3, (unsigned long long)ldl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 4, (unsigned long long)Dinv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 5, (unsigned long long)info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 6, (unsigned long long)(unsigned)col0 | ((unsigned long long)(unsigned)op << 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the task is in memory before `go` (earlier kernels' data: kernel boundary)
+  mb_store(&mb->go, seq);
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  bool ok = true;
+  while (mb_load(&mb->done) != seq) {
+    __builtin_amdgcn_s_sleep(2);
+    if (mb_load(&mb->err) != 0) { ok = false; break; }
+    if (__builtin_amdgcn_s_memrealtime() - t0 > LEAF_SERVER_LIMIT_TICKS) {
+      mb_store(&mb->err, 2u);
+      ok = false;
+      break;
+    }
+  }
+  if (!ok && info) atomicCAS(info, 0, LEAF_SERVER_INFO_POISON);
+}
+
+int launch_leaf_server(LeafMailbox* mb, unsigned first_seq, hipStream_t s) {
+  static_assert(offsetof(LeafMailbox, go) == 128 && offsetof(LeafMailbox, done) == 256 && offsetof(LeafMailbox, err) == 384,
+                "mailbox layout");
+  if (g_leaf_algo == 0) hipLaunchKernelGGL(leaf_server_kernel<0>, dim3(1), dim3(1024), 0, s, mb, first_seq);
+  else hipLaunchKernelGGL(leaf_server_kernel<1>, dim3(1), dim3(1024), 0, s, mb, first_seq);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_leaf_proxy(LeafMailbox* mb, unsigned seq, int op, const double* A, long lda, double* L, long ldl,
+                      double* Dinv, int* info, int col0, hipStream_t s) {
+  hipLaunchKernelGGL(leaf_proxy_kernel, dim3(1), dim3(64), 0, s, mb, seq, op, A, lda, L, ldl, Dinv, info, col0);
   GPK_HIP(hipGetLastError());
   return 0;
 }

@@ -187,6 +187,9 @@ int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended);
 /* pure v_mfma_f64_16x16x4_f64 issue loop on every CU: measured fp64 MFMA peak (TFLOP/s) of this device. */
 int gpk_bench_mfma_peak(int iters, double* tflops_out);
 int gpk_bench_mfma_peak2(int nacc, int waves_per_simd, int iters, double* tflops_out);
+/* the same loop with exactly waves_per_simd (1, 2, 4, 8) waves pinned on every SIMD through the LDS allocation;
+   out[6] = TFLOP/s, shader GHz, max / min waves per occupied SIMD, SIMDs occupied, TFLOP/s by the slowest wave's cycles. */
+int gpk_bench_mfma_pinned(int waves_per_simd, int iters, double* out);
 /* factor one 128x128 SPD tile: L_out (128x128 lower) and Dinv_out = inv(L). Returns info. */
 int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out);
 

@@ -1,0 +1,24 @@
+"""fp64 MFMA issue loop with the residency pinned (exactly W waves on every SIMD, through the LDS allocation) next to the
+dispatcher-placed loop of scripts/mfma_peak.py.  Usage: python scripts/mfma_pinned.py"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gptest_amd import _lib
+
+_lib.init()
+l = _lib.lib()
+o = (ctypes.c_double * 6)()
+t = (ctypes.c_double * 2)()
+for w in (1, 2, 4, 8):
+    for rep in range(2):
+        rc = l.gpk_bench_mfma_pinned(w, 40000, o)
+        assert rc == 0, _lib.last_error()
+        peak = 256 * 4 * 32 * o[1]
+        print("pinned   W=%d: %6.2f TFLOP/s (events) %6.2f (slowest wave's cycles) at %.3f GHz = %.1f%% / %.1f%% of %.1f | waves per SIMD max %d min %d, %d SIMDs"
+              % (w, o[0], o[5], o[1], 100 * o[0] / peak * 1e3 / 1e3, 100 * o[5] / peak, peak / 1e0, o[2], o[3], o[4]), flush=True)
+    if w <= 4:
+        l.gpk_bench_mfma_peak2(4, w, 40000, t)
+        print("unpinned W=%d: %6.2f TFLOP/s at %.3f GHz" % (w, t[0], t[1]), flush=True)
+_lib.shutdown()

@@ -50,6 +50,26 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t) {
   return 0;
 }
 
+// the resident leaf server on the CPU: the server launch is a no-op and a proxy does the tile itself (the host-side
+// session logic -- open, sequence numbers, quit from the destructor -- is what the sanitizer build is after)
+static unsigned g_sim_leaf_seq_expected = 0;
+int launch_leaf_server(LeafMailbox* mb, unsigned first_seq, hipStream_t) {
+  if (!mb) return gpk_set_err(-1, "sim: leaf server without a mailbox");
+  if (g_sim_leaf_seq_expected != 0) return gpk_set_err(-1, "sim: leaf server launched while another one is resident");
+  g_sim_leaf_seq_expected = first_seq;
+  return 0;
+}
+int launch_leaf_proxy(LeafMailbox* mb, unsigned seq, int op, const double* A, long lda, double* L, long ldl,
+                      double* Dinv, int* info, int col0, hipStream_t s) {
+  if (!mb || seq != g_sim_leaf_seq_expected) return gpk_set_err(-1, "sim: leaf proxy out of sequence (%u, expected %u)", seq, g_sim_leaf_seq_expected);
+  ++g_sim_leaf_seq_expected;
+  if (op == 1) {
+    g_sim_leaf_seq_expected = 0;  // the server has left
+    return 0;
+  }
+  return launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, s);
+}
+
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, int, hipStream_t) {
   static thread_local double t[128][128], inv[128][128];
   for (int i = 0; i < 128; ++i)

@@ -135,6 +135,11 @@ int main() {
 
   // ---- the posterior under every panel schedule the host code knows
   check_fit_predict(make_problem(300, 3, 40), "default");
+  opt("leaf_server", 1);  // session open / sequence numbers / quit from the destructor (the stand-ins check the order)
+  check_fit_predict(make_problem(800, 3, 40), "resident leaf server");
+  opt("nb", 128); check_fit_predict(make_problem(900, 2, 33), "resident leaf server, paired updates");
+  opt("nb", 256); opt("nb_auto", 1);
+  opt("leaf_server", 0);
   check_fit_predict(make_problem(1, 1, 3), "N=1");
   opt("nb", 128); check_fit_predict(make_problem(900, 2, 33), "nb=128 (paired updates)");
   opt("pair_update", 0); check_fit_predict(make_problem(700, 2, 33), "nb=128 one panel per update");

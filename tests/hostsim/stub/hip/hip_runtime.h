@@ -51,6 +51,7 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
 }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = new hostsim_stream{0}; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hostsim_stream{0}; return hipSuccess; }
 static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { *s = new hostsim_stream{1}; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

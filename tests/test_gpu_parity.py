@@ -145,6 +145,30 @@ def test_potrf_matches_numpy(gpk, N):
     assert np.all(np.triu(Ain, 1) == 0)
 
 
+@pytest.mark.parametrize("N", [640, 1500, 4096, 6000])
+def test_resident_leaf_server_is_bitwise_the_direct_leaf(gpk, N):
+    """Option leaf_server: the panel chain's leaves go through a mailbox to ONE resident workgroup (k_potf2.hip:
+    leaf_server_kernel / leaf_proxy_kernel) instead of one kernel launch per tile.  Same tile code, so the factor is
+    bit-identical; the paired (Npad <= 8192) and the plain look-ahead schedules, a failing pivot, and two factorisations
+    in a row (the second server queues behind the first one's quit message) are all covered."""
+    rng = np.random.RandomState(N)
+    Q = rng.randn(N, 64)
+    A = Q @ Q.T + N * np.eye(N)
+    L0 = A.copy()
+    assert gpk.lib().gpk_potrf(_ptr(L0), N) == 0, gpk.last_error()
+    gpk.set_option("leaf_server", 1)
+    for rep in range(2):
+        L1 = A.copy()
+        assert gpk.lib().gpk_potrf(_ptr(L1), N) == 0, gpk.last_error()
+        assert np.array_equal(L0, L1)
+    bad = N - 7
+    B = A.copy()
+    B[bad, bad] = -1.0
+    assert gpk.lib().gpk_potrf(_ptr(B), N) == bad + 1
+    gpk.set_option("leaf_server", 0)
+    assert gpk.lib().gpk_sync() == 0
+
+
 @pytest.mark.parametrize("N,bad", [(5, 3), (300, 131), (520, 519)])
 def test_potrf_not_positive_definite(gpk, N, bad):
     """LAPACK-style info > 0 -> the binding raises numpy.linalg.LinAlgError (what GPpref.py:133 catches)."""
