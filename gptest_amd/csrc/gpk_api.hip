@@ -278,6 +278,9 @@ int gpk_set_option(const char* key, double value) {
     G.test_gemm_k1 = (int)value;
   } else if (k == "pair_update") {
     G.pair_update = (int)value;
+  } else if (k == "gemm_pipe") {
+    extern int g_gemm_pipe;
+    g_gemm_pipe = (int)value ? 1 : 0;
   } else if (k == "leaf_server") {
     G.leaf_server = (int)value ? 1 : 0;
   } else if (k == "pipe_interleave") {
@@ -322,6 +325,7 @@ double gpk_get_option(const char* key) {
   if (k == "small_tile_below") return G.small_tile_below;
   if (k == "pair_update") return G.pair_update;
   if (k == "leaf_server") return G.leaf_server;
+  if (k == "gemm_pipe") { extern int g_gemm_pipe; return g_gemm_pipe; }
   if (k == "cu_reserved") return G.cu_reserved ? G.ncu_reserved : 0;
   if (k == "pipe_interleave") return G.pipe_interleave;
   if (k == "fuse_predict") return G.fuse_predict;

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 }
 
 int g_gemm_variant = 8;  // 8: 8-wave 128x128 kernel (default); 4: the 4-wave kernel
+int g_gemm_pipe = 1;     // 8-wave kernel: software-pipelined slab loop (0: the plain loop)
 
 // ---------------------------------------------------------------------------------------------
 // 8-wave variant of the 128x128 tile: wave tile 64x32 (4x2 MFMA tiles, 64 accumulator VGPRs), <=128
@@ -159,7 +160,7 @@ int g_gemm_variant = 8;  // 8: 8-wave 128x128 kernel (default); 4: the 4-wave ke
 // sub mode: the accumulators START as C (loaded while the first K-slab is in flight) and A is
 // negated on its way into LDS, so the MFMA chain itself yields C - A*B^T and the epilogue is
 // store-only (no load -> subtract -> store dependency at the end of every tile).
-template <bool TWOSEG, int DBG = 0>  // TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update)
+template <bool TWOSEG, int DBG = 0, bool PIPE = false>  // TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update)
 __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   constexpr int BT = 128;
   __shared__ double lds[2 * 2 * BT * LDS_LD];
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   } else {
     brow0 = (long)tj * BT;
   }
-  const double* Ag = g.A + (long)ti * BT * g.lda;
-  const double* Bg = g.B + brow0 * g.ldb;
+  const double* Ag = (DBG & 16) ? g.A : g.A + (long)ti * BT * g.lda;  // DBG 16: every tile reads tile 0's first slab (cache hits)
+  const double* Bg = (DBG & 16) ? g.B : g.B + brow0 * g.ldb;
   const int lrow = tid >> 3, lchk = (tid & 7) * 2;  // 64 rows x 8 chunks per pass
   const int fr = lane & 15, fg = lane >> 4;
   double* Cw = g.C + ((long)ti * BT + wm * 64) * g.ldc + (long)tj * BT + wn * 32;  // wave-uniform
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   const double* Ag2 = TWOSEG ? g.A2 + (long)ti * BT * g.lda2 : Ag;
   const double* Bg2 = TWOSEG ? g.B2 + brow0 * g.ldb2 : Bg;
   auto gload = [&](int kt) {
+    if (DBG & 16) kt = 0;
     if (TWOSEG) {
       // wave-uniform segment select: slabs [0, nk1) from (A, B), the rest from (A2, B2).  Both segments have the
       // same leading dimensions (host check), so only the scalar base and slab index differ from the plain path:
@@ -290,6 +292,68 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   gload(0);
   lstore(0);
   __syncthreads();
+  if constexpr (PIPE) {
+    // Software-pipelined slab loop: the fragments of k-step s+1 are read from LDS while the MFMAs of k-step s run
+    // (two fragment sets, the same 24 registers the plain loop holds for two k-steps at once), the next slab goes to
+    // LDS before the LAST k-step and the barrier sits in front of that k-step, so that the first fragments of the
+    // next slab are read under its MFMAs.  Same MFMA order over k: bitwise the plain loop's result.
+    double pa[2][4], pb[2][2];
+    const double* Ab0 = As + (wm * 64 + fr) * LDS_LD + fg;
+    const double* Bb0 = Bs + (wn * 32 + fr) * LDS_LD + fg;
+    auto rd = [&](int slot, int buf, int kk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pa[slot][i] = Ab0[(buf * BT + i * 16) * LDS_LD + kk];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pb[slot][j] = Bb0[(buf * BT + j * 16) * LDS_LD + kk];
+    };
+    auto mm = [&](int slot) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[slot][i], pb[slot][j], acc[i][j], 0, 0, 0);
+    };
+    // Staging (one register set): the slab written to LDS right after barrier B_kt is slab kt+2, into the buffer the
+    // barrier has just released; its global loads were issued one slab earlier, and the registers are refilled with
+    // slab kt+3 at once.  So a slab is in LDS a whole slab before it is read: no barrier ever waits on a fresh
+    // ds_write, and the global loads have a full slab to land.
+    if (nk > 1) gload(1);
+    rd(0, 0, 0);
+    if (nk > 1) {
+      lstore(1);
+      if (nk > 2) gload(2);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      __builtin_amdgcn_sched_barrier(0);
+      rd(1, buf, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(0);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(0, buf, 8);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(1);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(1, buf, 12);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the last fragments of this slab must be IN REGISTERS before the barrier releases its buffer; left alone the
+      // compiler sinks those ds_reads below the barrier (legal for a fence, fatal here: the buffer is rewritten behind it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pa[1][i]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(pb[1][j]));
+      if (!(DBG & 2)) __syncthreads();  // B_kt: slab kt+1 (written a slab ago) visible, this slab's buffer released
+      if (kt + 1 < nk) rd(0, buf ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(DBG & 1) && kt + 2 < nk) {
+        lstore(buf);
+        if (kt + 3 < nk) gload(kt + 3);
+      }
+    }
+  } else {
   double fa[4], fb[2];
   if (DBG & 4) {
 #pragma unroll
@@ -316,6 +380,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     }
     if (!(DBG & 1) && kt + 1 < nk) lstore(buf ^ 1);
     if (!(DBG & 2)) __syncthreads();
+  }
   }
   if (DBG & 8) {
     double t = 0;
@@ -368,17 +433,47 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
       const long nsq = g.lower ? SN * (SN + 1) / 2 + (SM - SN) * SN : SM * SN;
       nblk = ((nsq + 7) / 8) * 8 * 64;
     }
+    // g_gemm_pipe (option "gemm_pipe", default 1): the software-pipelined slab loop; 0 = the plain loop (bitwise the same C).
+    const dim3 grid((unsigned)nblk), block(512);
+#ifdef GPK_GEMM_DBG_VARIANTS
+    // timing-only builds of the kernel (make DBG=1; scripts/gemm_dbg.py): GPK_GEMM_DBG bits 1 no global loads / LDS
+    // writes in the loop, 2 no barriers, 4 no LDS reads (plain loop only), 8 no C load / store, 16 every tile reads tile
+    // 0's first slab; GPK_GEMM_DYNLDS=<bytes> of extra LDS per workgroup (20480: one workgroup per CU).  Wrong results.
     static const int dbg = getenv("GPK_GEMM_DBG") ? atoi(getenv("GPK_GEMM_DBG")) : 0;
-    if (g.k1 > 0) hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else if (dbg == 1) hipLaunchKernelGGL((gemm_nt8_kernel<false, 1>), dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else if (dbg == 2) hipLaunchKernelGGL((gemm_nt8_kernel<false, 2>), dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else if (dbg == 3) hipLaunchKernelGGL((gemm_nt8_kernel<false, 3>), dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else if (dbg == 4) hipLaunchKernelGGL((gemm_nt8_kernel<false, 4>), dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else if (dbg == 5) hipLaunchKernelGGL((gemm_nt8_kernel<false, 5>), dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else if (dbg == 7) hipLaunchKernelGGL((gemm_nt8_kernel<false, 7>), dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else if (dbg == 8) hipLaunchKernelGGL((gemm_nt8_kernel<false, 8>), dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else if (dbg == 15) hipLaunchKernelGGL((gemm_nt8_kernel<false, 15>), dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL(gemm_nt8_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, s, g);
+    static const int dyn = getenv("GPK_GEMM_DYNLDS") ? atoi(getenv("GPK_GEMM_DYNLDS")) : 0;
+    if ((dbg || dyn) && g.k1 == 0) {
+#define GPK_DBG_LAUNCH(D, P)                                                                                              \
+  do {                                                                                                                    \
+    if (dyn > 0) (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<false, D, P>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); \
+    hipLaunchKernelGGL((gemm_nt8_kernel<false, D, P>), grid, block, dyn, s, g);                                           \
+  } while (0)
+      if (g_gemm_pipe) {
+        switch (dbg) {
+          case 1: GPK_DBG_LAUNCH(1, true); break;
+          case 2: GPK_DBG_LAUNCH(2, true); break;
+          case 3: GPK_DBG_LAUNCH(3, true); break;
+          case 8: GPK_DBG_LAUNCH(8, true); break;
+          case 11: GPK_DBG_LAUNCH(11, true); break;
+          case 16: GPK_DBG_LAUNCH(16, true); break;
+          default: GPK_DBG_LAUNCH(0, true); break;
+        }
+      } else {
+        switch (dbg) {
+          case 1: GPK_DBG_LAUNCH(1, false); break;
+          case 2: GPK_DBG_LAUNCH(2, false); break;
+          case 4: GPK_DBG_LAUNCH(4, false); break;
+          case 7: GPK_DBG_LAUNCH(7, false); break;
+          case 8: GPK_DBG_LAUNCH(8, false); break;
+          case 15: GPK_DBG_LAUNCH(15, false); break;
+          default: GPK_DBG_LAUNCH(0, false); break;
+        }
+      }
+#undef GPK_DBG_LAUNCH
+    } else
+#endif
+    if (g.k1 > 0) hipLaunchKernelGGL(gemm_nt8_kernel<true>, grid, block, 0, s, g);
+    else if (g_gemm_pipe) hipLaunchKernelGGL((gemm_nt8_kernel<false, 0, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL(gemm_nt8_kernel<false>, grid, block, 0, s, g);
   }
   else if (tile128)
     hipLaunchKernelGGL(gemm_nt_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, g);

@@ -1,5 +1,6 @@
 """fp64 MFMA issue loop with the residency pinned (exactly W waves on every SIMD, through the LDS allocation) next to the
-dispatcher-placed loop of scripts/mfma_peak.py.  Usage: python scripts/mfma_pinned.py"""
+dispatcher-placed loop of scripts/mfma_peak.py.  Environment: GPK_BENCH_MASKED=1 runs the pinned loop on the CU-masked update stream, GPK_BENCH_CUS=<n> sizes the grid
+for n CUs, GPK_BENCH_THREADS=512|1024 changes the workgroup size (W = 4 only).  Usage: python scripts/mfma_pinned.py"""
 import ctypes
 import os
 import sys
@@ -15,9 +16,9 @@ for w in (1, 2, 4, 8):
     for rep in range(2):
         rc = l.gpk_bench_mfma_pinned(w, 40000, o)
         assert rc == 0, _lib.last_error()
-        peak = 256 * 4 * 32 * o[1]
+        peak = 256 * 4 * 32 * o[1] * 1e-3  # TFLOP/s at the measured shader clock
         print("pinned   W=%d: %6.2f TFLOP/s (events) %6.2f (slowest wave's cycles) at %.3f GHz = %.1f%% / %.1f%% of %.1f | waves per SIMD max %d min %d, %d SIMDs"
-              % (w, o[0], o[5], o[1], 100 * o[0] / peak * 1e3 / 1e3, 100 * o[5] / peak, peak / 1e0, o[2], o[3], o[4]), flush=True)
+              % (w, o[0], o[5], o[1], 100 * o[0] / peak, 100 * o[5] / peak, peak, o[2], o[3], o[4]), flush=True)
     if w <= 4:
         l.gpk_bench_mfma_peak2(4, w, 40000, t)
         print("unpinned W=%d: %6.2f TFLOP/s at %.3f GHz" % (w, t[0], t[1]), flush=True)

@@ -9,6 +9,7 @@
 
 thread_local dim3 blockIdx, threadIdx, blockDim, gridDim;
 int g_gemm_variant = 8;
+int g_gemm_pipe = 1;
 int g_leaf_algo = 1;
 
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t) {

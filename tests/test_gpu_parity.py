@@ -70,6 +70,32 @@ def test_mfma_gemm_nt_lower_trapezoid(gpk, m, n, k, tile):
         np.testing.assert_array_equal(C[~mask], C0[~mask])
 
 
+@pytest.mark.parametrize("m,n,k,sub,lower", [(256, 384, 16, 1, 0), (256, 384, 32, 0, 0), (384, 256, 48, 1, 0),
+                                             (1152, 1152, 80, 1, 1), (2304, 512, 256, 1, 1), (512, 640, 512, 1, 0)])
+def test_pipelined_slab_loop_is_bitwise_the_plain_loop(gpk, m, n, k, sub, lower):
+    """Option gemm_pipe (default 1): the 8-wave kernel's software-pipelined slab loop -- fragments of the next k-step
+    read under the MFMAs of the current one, the next-but-one slab written to LDS right after the barrier that releases
+    its buffer -- keeps the MFMA order over k, so C is bit for bit the plain loop's, for 1, 2, 3 and more slabs."""
+    rng = np.random.RandomState(m + n + k)
+    A = rng.randn(m, k)
+    B = np.ascontiguousarray(A[:n]) if lower else rng.randn(n, k)
+    C0 = rng.randn(m, n)
+    out = []
+    for pipe in (0, 1):
+        gpk.set_option("gemm_pipe", pipe)
+        C = C0.copy()
+        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, 128) == 0, gpk.last_error()
+        out.append(C)
+    assert np.array_equal(out[0], out[1])
+    ref = C0 - A @ B.T if sub else A @ B.T
+    mask = np.ones((m, n), bool)
+    if lower:
+        mask[:] = False
+        for ti in range(m // 128):
+            mask[ti * 128:(ti + 1) * 128, :min(n, (ti + 1) * 128)] = True
+    np.testing.assert_allclose(out[1][mask], ref[mask], rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize("sub", [0, 1])
 def test_tile_sizes_round_identically(gpk, sub):
     """The schedule picks 64x64 or 128x128 tiles by launch size; the factor must not depend on that choice
