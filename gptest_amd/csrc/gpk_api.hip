@@ -280,7 +280,7 @@ int gpk_set_option(const char* key, double value) {
     G.pair_update = (int)value;
   } else if (k == "gemm_pipe") {
     extern int g_gemm_pipe;
-    g_gemm_pipe = (int)value ? 1 : 0;
+    g_gemm_pipe = (int)value;
   } else if (k == "leaf_server") {
     G.leaf_server = (int)value ? 1 : 0;
   } else if (k == "pipe_interleave") {

@@ -19,6 +19,7 @@
 //   * 2 workgroups per CU (<=256 VGPR, 72 KiB LDS each) so one workgroup's C
 //     read-modify-write epilogue overlaps the other's MFMA main loop.
 #include "gpk_internal.h"
+#include <type_traits>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 }
 
 int g_gemm_variant = 8;  // 8: 8-wave 128x128 kernel (default); 4: the 4-wave kernel
-int g_gemm_pipe = 1;     // 8-wave kernel: software-pipelined slab loop (0: the plain loop)
+int g_gemm_pipe = 2;     // 8-wave kernel: 2 software-pipelined slab loop staged by LDS-DMA (default), 1 the same with register staging, 0 the plain loop
 
 // ---------------------------------------------------------------------------------------------
 // 8-wave variant of the 128x128 tile: wave tile 64x32 (4x2 MFMA tiles, 64 accumulator VGPRs), <=128
@@ -160,7 +161,18 @@ int g_gemm_pipe = 1;     // 8-wave kernel: software-pipelined slab loop (0: the 
 // sub mode: the accumulators START as C (loaded while the first K-slab is in flight) and A is
 // negated on its way into LDS, so the MFMA chain itself yields C - A*B^T and the epilogue is
 // store-only (no load -> subtract -> store dependency at the end of every tile).
-template <bool TWOSEG, int DBG = 0, bool PIPE = false>  // TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update)
+// one wave-instruction of LDS-DMA: every lane's 16 bytes at gsrc go to LDS byte address lds_dst + 16 * lane (lds_dst wave-uniform);
+// no VGPR destination, counted on vmcnt, invisible to the compiler's own wait bookkeeping
+// (source = wave-uniform base + per-lane 32-bit byte offset: one address VGPR per operand for the whole kernel)
+static __device__ __forceinline__ void glds16(const double* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+template <bool TWOSEG, int DBG = 0, bool PIPE = false, bool GLDS = false, bool NEG = false>  // TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update)
 __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   constexpr int BT = 128;
   __shared__ double lds[2 * 2 * BT * LDS_LD];
@@ -289,6 +301,93 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   };
 
   const int nk = g.k / BK;
+  if constexpr (GLDS) {
+    // Staging by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no negation pass (the MFMA
+    // negates A: BLGP bit 0 of the f64 MFMAs).  The LDS image is lane-linear per wave-instruction -- 8 rows of 128 bytes
+    // -- so rows are unpadded and the bank conflicts are swizzled away on the SOURCE side: LDS (row r, 16-byte chunk c)
+    // holds global chunk c ^ ((r >> 1) & 7) of that row's slab, and the fragment reads apply the same XOR: the 32 lanes
+    // of a ds_read_b64 group (16 rows x 2 halves of one chunk column) then cover all 64 banks once.
+    constexpr int OPD = BT * BK;   // doubles per operand and stage (128 rows x 16)
+    constexpr int STG = 2 * OPD;   // A then B: 32 KiB per stage, two stages
+    typedef __attribute__((address_space(3))) double lds_double;
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_double*)lds;
+    const int rr = wid * 8 + (lane >> 3);  // the row this lane fills (and rr + 64)
+    const int gch = ((lane & 7) ^ ((rr >> 1) & 7)) * 2;
+    const unsigned voA = (unsigned)(((long)rr * g.lda + gch) * 8);  // < 4 GiB: 128 rows of one operand (host check)
+    const unsigned voB = (unsigned)(((long)rr * g.ldb + gch) * 8);
+    const long a64 = 64 * g.lda, b64 = 64 * g.ldb;
+    const int nk1g = TWOSEG ? g.k1 / BK : 0;
+    const double* Ag2g = TWOSEG ? g.A2 + (long)ti * BT * g.lda2 : Ag;  // second K segment: same leading dimensions (host check)
+    const double* Bg2g = TWOSEG ? g.B2 + brow0 * g.ldb2 : Bg;
+    auto dma = [&](int kt, int buf) {
+      const unsigned dst = lds0 + (unsigned)((buf * STG + wid * 8 * BK) * 8);
+      const bool first = !TWOSEG || kt < nk1g;  // scalar select of the segment: slabs [0, nk1) from (A, B), the rest from (A2, B2)
+      const double* Ap = (first ? Ag : Ag2g) + (first ? kt : kt - nk1g) * BK;
+      const double* Bp = (first ? Bg : Bg2g) + (first ? kt : kt - nk1g) * BK;
+      glds16(Ap, voA, dst);
+      glds16(Ap + a64, voA, dst + 64 * BK * 8);
+      glds16(Bp, voB, dst + OPD * 8);
+      glds16(Bp + b64, voB, dst + OPD * 8 + 64 * BK * 8);
+    };
+    const int fsw = (fr >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = 4 * q + fg;
+      koff[q] = ((k >> 1) ^ fsw) * 2 + (k & 1);
+    }
+    const double* Ab0 = lds + (wm * 64 + fr) * BK;
+    const double* Bb0 = lds + OPD + (wn * 32 + fr) * BK;
+    double pa[2][4], pb[2][2];
+    auto rd = [&](int slot, int buf, int q) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pa[slot][i] = Ab0[buf * STG + i * 16 * BK + koff[q]];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pb[slot][j] = Bb0[buf * STG + j * 16 * BK + koff[q]];
+    };
+    {
+      constexpr int NEGA = NEG ? 1 : 0;  // the host instantiates NEG = (sub != 0)
+      auto mm = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[slot][i], pb[slot][j], acc[i][j], 0, 0, NEGA);
+      };
+      dma(0, 0);
+      if (nk > 1) dma(1, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      rd(0, 0, 0);
+      for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        rd(1, buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(0, buf, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(1, buf, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pa[1][i]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(pb[1][j]));
+        // B_kt: every wave's DMA of slab kt+1 (issued a slab ago) has landed, this slab's buffer is released
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(DBG & 2)) __syncthreads();
+        if (kt + 1 < nk) rd(0, buf ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 1) && kt + 2 < nk) dma(kt + 2, buf);
+      }
+    }
+  } else {
   gload(0);
   lstore(0);
   __syncthreads();
@@ -382,6 +481,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     if (!(DBG & 2)) __syncthreads();
   }
   }
+  }
   if (DBG & 8) {
     double t = 0;
 #pragma unroll
@@ -413,6 +513,8 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
     return gpk_set_err(-1, "gemm_nt: bad shape m=%d n=%d k=%d (tile %d)", g.m, g.n, g.k, BT);
   if ((g.lda & 1) || (g.ldb & 1) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15))
     return gpk_set_err(-1, "gemm_nt: operands must be 16-byte aligned with even leading dimensions");
+  if (g.lda >= (1l << 22) || g.ldb >= (1l << 22))  // LDS-DMA staging: 128 rows of an operand within a 32-bit byte offset
+    return gpk_set_err(-1, "gemm_nt: leading dimensions must stay below 2^22");
   if (g.k1 > 0) {
     if (!tile128 || g_gemm_variant != 8 || g.cyc_P != 0)
       return gpk_set_err(-1, "gemm_nt: a second K segment needs the 8-wave single-GPU kernel");
@@ -471,7 +573,11 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
 #undef GPK_DBG_LAUNCH
     } else
 #endif
-    if (g.k1 > 0) hipLaunchKernelGGL(gemm_nt8_kernel<true>, grid, block, 0, s, g);
+    if (g.k1 > 0 && g_gemm_pipe == 2 && g.sub) hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, true, true, true>), grid, block, 0, s, g);
+    else if (g.k1 > 0 && g_gemm_pipe == 2) hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, true, true, false>), grid, block, 0, s, g);
+    else if (g.k1 > 0) hipLaunchKernelGGL(gemm_nt8_kernel<true>, grid, block, 0, s, g);
+    else if (g_gemm_pipe == 2 && g.sub) hipLaunchKernelGGL((gemm_nt8_kernel<false, 0, true, true, true>), grid, block, 0, s, g);
+    else if (g_gemm_pipe == 2) hipLaunchKernelGGL((gemm_nt8_kernel<false, 0, true, true, false>), grid, block, 0, s, g);
     else if (g_gemm_pipe) hipLaunchKernelGGL((gemm_nt8_kernel<false, 0, true>), grid, block, 0, s, g);
     else hipLaunchKernelGGL(gemm_nt8_kernel<false>, grid, block, 0, s, g);
   }

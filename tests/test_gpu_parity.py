@@ -81,12 +81,20 @@ def test_pipelined_slab_loop_is_bitwise_the_plain_loop(gpk, m, n, k, sub, lower)
     B = np.ascontiguousarray(A[:n]) if lower else rng.randn(n, k)
     C0 = rng.randn(m, n)
     out = []
-    for pipe in (0, 1):
+    for pipe in (0, 1, 2):  # 2: staging by LDS-DMA (swizzled unpadded image, A negated by the MFMA itself)
         gpk.set_option("gemm_pipe", pipe)
         C = C0.copy()
         assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, 128) == 0, gpk.last_error()
         out.append(C)
     assert np.array_equal(out[0], out[1])
+    assert np.array_equal(out[0], out[2])
+    if k >= 32:  # the two-segment form (paired trailing update), register-staged and LDS-DMA-staged
+        for pipe in (0, 2):
+            gpk.set_option("gemm_pipe", pipe)
+            gpk.set_option("test_gemm_k1", 16 if k < 256 else 128)
+            C = C0.copy()
+            assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, 128) == 0, gpk.last_error()
+            assert np.array_equal(out[0], C)
     ref = C0 - A @ B.T if sub else A @ B.T
     mask = np.ones((m, n), bool)
     if lower:
