@@ -38,7 +38,7 @@ int gpk_init(int device) {
     return gpk_set_err(-2, "gpk_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
                        prop.gcnArchName);
   // Stream layout.  The leaf kernel needs 132 KiB of LDS, i.e. a CU with no trailing-update
-  // workgroup resident; behind a queue of thousands of 72 KiB GEMM workgroups it would starve.
+  // workgroup resident; behind a queue of thousands of 64 KiB GEMM workgroups it would starve.
   // So one CU is reserved (CU mask) for the leaf stream and the GEMM streams get the other 255.
   const int ncu = prop.multiProcessorCount;
   const char* env_res = getenv("GPK_RESERVE_CU");  // 0: nothing masked (then option leaf_server defaults to 1)

@@ -16,8 +16,8 @@
 //   * C/D fragment (f64 only!): col = lane&15, row = (lane>>4) + 4*reg.
 //   * LDS row stride BK+2 doubles: the 32 lanes of a ds_read_b64 group touch
 //     dword banks 36*r + 2*g (+0,1) mod 64 -> all 64 banks once: conflict-free.
-//   * 2 workgroups per CU (<=256 VGPR, 72 KiB LDS each) so one workgroup's C
-//     read-modify-write epilogue overlaps the other's MFMA main loop.
+//   * 2 workgroups per CU (64 KiB of LDS each in the LDS-DMA form, 72 KiB register-staged) so one
+//     workgroup's C tile hand-over overlaps the other's MFMA main loop.
 #include "gpk_internal.h"
 #include <type_traits>
 
@@ -154,13 +154,16 @@ int g_gemm_pipe = 2;     // 8-wave kernel: 2 software-pipelined slab loop staged
 
 // ---------------------------------------------------------------------------------------------
 // 8-wave variant of the 128x128 tile: wave tile 64x32 (4x2 MFMA tiles, 64 accumulator VGPRs), <=128
-// VGPRs per wave, two workgroups per CU = FOUR waves per SIMD.  Measured on MI355X with a pure
-// v_mfma_f64_16x16x4_f64 issue loop (gpk_bench_mfma_peak2): one wave per SIMD reaches 52% of the
-// matrix-pipe peak, two 69%, four 82% -- a single wave cannot issue f64 MFMAs back to back, so
-// occupancy, not instruction-level parallelism, is what fills the pipe.
-// sub mode: the accumulators START as C (loaded while the first K-slab is in flight) and A is
-// negated on its way into LDS, so the MFMA chain itself yields C - A*B^T and the epilogue is
-// store-only (no load -> subtract -> store dependency at the end of every tile).
+// VGPRs per wave, two workgroups per CU = FOUR waves per SIMD in two independent barrier domains.  The matrix
+// pipe itself is saturated by ONE wave per SIMD (gpk_bench_mfma_pinned: 98-99 % of 2048 flop / 64 cycles / SIMD
+// at W = 1, 2, 4, 8; the n/(n+1) figures of gpk_bench_mfma_peak2 are workgroup placement); what the second
+// workgroup buys is cover for the first one's barrier, C tile and turnover (one workgroup per CU: 62 TFLOP/s,
+// two: 66-69).
+// sub mode: the accumulators START as C and A enters the MFMA negated (in the DMA form by the instruction's
+// neg bit, in the register-staged forms on its way into LDS), so the MFMA chain itself yields C - A*B^T and
+// the epilogue is store-only (no load -> subtract -> store dependency at the end of every tile).
+// Three forms of the slab loop, bitwise the same C (option gemm_pipe): 2 LDS-DMA staging + fragment prefetch
+// (default), 1 register staging + fragment prefetch, 0 the plain loop.  DESIGN.md section 6 has the numbers.
 // one wave-instruction of LDS-DMA: every lane's 16 bytes at gsrc go to LDS byte address lds_dst + 16 * lane (lds_dst wave-uniform);
 // no VGPR destination, counted on vmcnt, invisible to the compiler's own wait bookkeeping
 // (source = wave-uniform base + per-lane 32-bit byte offset: one address VGPR per operand for the whole kernel)
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   const unsigned c_off = (unsigned)fg * (unsigned)g.ldc + (unsigned)fr;
 
   d4 acc[4][2];
+  auto init_acc = [&]() {
   if (g.sub && !(DBG & 8)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -262,6 +266,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
   }
+  };
+  if (!GLDS) init_acc();  // (LDS-DMA staging: the first two slabs are requested BEFORE the C tile, which queues behind them in the load path)
 
   d2 ra[2], rb[2];
   const int nk1 = TWOSEG ? g.k1 / BK : 0;  // slabs of the first K segment
@@ -355,6 +361,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
       };
       dma(0, 0);
       if (nk > 1) dma(1, 1);
+      init_acc();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       rd(0, 0, 0);
@@ -549,7 +556,22 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
     if (dyn > 0) (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<false, D, P>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); \
     hipLaunchKernelGGL((gemm_nt8_kernel<false, D, P>), grid, block, dyn, s, g);                                           \
   } while (0)
-      if (g_gemm_pipe) {
+      if (g_gemm_pipe == 2 && g.sub) {
+#define GPK_DBG_LAUNCH_G(D)                                                                                               \
+  do {                                                                                                                    \
+    if (dyn > 0) (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<false, D, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); \
+    hipLaunchKernelGGL((gemm_nt8_kernel<false, D, true, true, true>), grid, block, dyn, s, g);                            \
+  } while (0)
+        switch (dbg) {
+          case 1: GPK_DBG_LAUNCH_G(1); break;
+          case 2: GPK_DBG_LAUNCH_G(2); break;
+          case 8: GPK_DBG_LAUNCH_G(8); break;
+          case 9: GPK_DBG_LAUNCH_G(9); break;
+          case 16: GPK_DBG_LAUNCH_G(16); break;
+          default: GPK_DBG_LAUNCH_G(0); break;
+        }
+#undef GPK_DBG_LAUNCH_G
+      } else if (g_gemm_pipe) {
         switch (dbg) {
           case 1: GPK_DBG_LAUNCH(1, true); break;
           case 2: GPK_DBG_LAUNCH(2, true); break;

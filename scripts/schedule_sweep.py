@@ -36,6 +36,11 @@ elif len(sys.argv) > 2 and sys.argv[2] == "panels":
     for big, until in [(512, 4096), (512, 6144), (512, 12288), (1024, 8192), (1024, 4096), (768, 6144)]:
         for small_from in (2048, 4096):
             configs.append(dict(nb_big=big, nb_big_until=until, nb_small_from=small_from))
+elif len(sys.argv) > 2 and sys.argv[2] == "misc":
+    configs += [dict(xcd_sq_min_tiles=0), dict(xcd_sq_min_tiles=2048), dict(xcd_sq_min_tiles=1 << 30), dict(pair_update=2), dict(pair_update=0),
+                dict(small_tile_below=128), dict(small_tile_below=512), dict(pred_small_below=150), dict(pred_small_below=600),
+                dict(nb_big_until=4096), dict(nb_big_until=12288), dict(nb_small_from=4096), dict(nb_small_from=1024),
+                dict(nb_outer=2048, outer_until=8192, outer_from=8192), dict(nb_outer=1024, outer_until=4096, outer_from=8192)]
 elif len(sys.argv) > 2 and sys.argv[2] == "short":
     configs += [dict(nb_outer=1024, outer_until=4096, outer_from=8192), dict(nb_outer=2048, outer_until=4096, outer_from=8192),
                 dict(nb_outer=2048, outer_until=8192, outer_from=8192),
@@ -49,7 +54,8 @@ else:
                 dict(nb_outer=1536, outer_until=4096, outer_from=8192),
                 dict(nb_outer=3072, outer_until=4096, outer_from=8192)]
 print("GPK_RESERVE_PER_XCD=%s GPU_MAX_HW_QUEUES=%s" % (os.environ.get("GPK_RESERVE_PER_XCD"), os.environ.get("GPU_MAX_HW_QUEUES")), flush=True)
-defaults = {k: _lib.get_option(k) for k in ("nb_outer", "outer_until", "outer_from", "nb_big_until", "nb_big", "tail_rows", "nb_small_from")}
+defaults = {k: _lib.get_option(k) for k in ("nb_outer", "outer_until", "outer_from", "nb_big_until", "nb_big", "tail_rows", "nb_small_from",
+                                             "xcd_sq_min_tiles", "pair_update", "small_tile_below", "pred_small_below")}
 for cfg in configs:
     for k, v in defaults.items():
         _lib.set_option(k, v)
