@@ -239,7 +239,7 @@ def main():
             "config": {"workload": "GPr regression N=%d d=%d RBF fp64, M=%d test points%s" % (
                 N, d, M, " (BASELINE configs[2], the size the metric is quoted on)" if (N, d) == (16384, 8) else
                 " (BASELINE configs[1])" if (N, d) == (4096, 4) else ""),
-                       "panel_schedule": "512/256/128 columns by remaining size (nb_auto)" if world == 1 else "uniform %d" % nb,
+                       "panel_schedule": "512/256/128 columns by remaining size (nb_auto), tile pipeline for the last 4096 columns" if world == 1 else "uniform %d" % nb,
                        "parallelism": "1 GPU" if world == 1 else "block-cyclic panels x%d, RCCL broadcast" % world},
             "roofline": {"kernel": "gemm_nt8_kernel (Cholesky trailing update, fp64 MFMA 16x16x4)", "bound": "mfma",
                          "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",

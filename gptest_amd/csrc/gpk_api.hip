@@ -254,9 +254,12 @@ int gpk_set_option(const char* key, double value) {
     G.xcd_sq = (int)value;
   } else if (k == "xcd_sq_min_tiles") {
     G.xcd_sq_min_tiles = (int)value;
+  } else if (k == "tail_stream") {
+    if (G.tail_rows > 0) return gpk_set_err(-1, "option tail_stream must be set while tail_rows is 0");
+    G.tail_stream = (int)value ? 1 : 0;
   } else if (k == "tail_rows") {
     G.tail_rows = (int)value;
-    if (G.inited && G.tail_rows > 0 && !G.s_rows) {
+    if (G.inited && G.tail_rows > 0 && !G.s_rows && G.tail_stream) {
       int lo_ = 0, hi_ = 0;
       GPK_HIP(hipDeviceGetStreamPriorityRange(&lo_, &hi_));
       GPK_HIP(hipStreamCreateWithPriority(&G.s_rows, hipStreamNonBlocking, hi_));
@@ -332,6 +335,7 @@ double gpk_get_option(const char* key) {
   if (k == "solve_gemm_above") return G.solve_gemm_above;
   if (k == "stamps") return G.stamps;
   if (k == "tail_rows") return G.tail_rows;
+  if (k == "tail_stream") return G.tail_stream;
   if (k == "potrf_tail_from") { extern int g_potrf_tail_from; return g_potrf_tail_from; }
   if (k == "test_gemm_k1") return G.test_gemm_k1;
   if (k == "leaf_algo") { extern int g_leaf_algo; return g_leaf_algo; }

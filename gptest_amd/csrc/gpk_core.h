@@ -38,7 +38,7 @@ struct Runtime {
   int nb = 256;
   // single-GPU panel schedule: wide panels (K = nb_big) while the trailing matrix is large and the panel
   // chain hides behind the update, nb in the middle, nb_small at the tail where the chain IS the critical path
-  int nb_big = 512, nb_big_until = 8192, nb_small = 128, nb_small_from = 2048, nb_auto = 1;
+  int nb_big = 512, nb_big_until = 8192, nb_small = 128, nb_small_from = 4096, nb_auto = 1;
   // two-level blocking (single GPU, nb_auto): OUTER panels of nb_outer columns are applied to the trailing matrix as
   // ONE update with K = nb_outer (the kernel does 56 TFLOP/s at K = 2048 against 44 at K = 256: the C tile traffic
   // and the accumulator hand-over amortise over 8x the flops); inside an outer block column the panels above are the
@@ -50,7 +50,8 @@ struct Runtime {
   int dist_group = 2;   // panels per ownership block of a block-cyclic (multi-GPU) model
   // tile pipeline (potrf_tail) for the chain-bound last tail_rows columns (needs 128-wide panels there: nb_small_from);
   // 0 = the panel-level look-ahead everywhere
-  int tail_rows = 0;
+  int tail_rows = 4096;
+  int tail_stream = 0;  // the tile pipeline's full-height GEMMs: 0 in front of the bulk on the update stream (default), 1 on a stream of their own (s_rows, a FOURTH stream)
   double last_potrf_enqueue_ms = 0.0, last_pipe_enqueue_ms = 0.0;  // host time spent queueing the last factorisation
   int timing = 0;
   int stamps = 0;  // diagnostic: device-side progress stamps per panel (gpk_get_option("stamp_panel_<p>" / "stamp_subst_<p>"), scripts/stamp_steps.py)

@@ -515,7 +515,7 @@ static int potrf_device_paired(gpk_model* m, const std::function<int(int)>* afte
 // Each element receives the same rank-128 updates in the same order as in the panel-level schedule with 128-wide
 // panels, so the factor is bit-identical to it (tests).  `ev_prev_rest`: what plays REST(p_first - 1).
 static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const std::function<int(int)>* after_panel) {
-  hipStream_t sm = G.s_main, sc = G.s_panel, sr = G.s_rows;
+  hipStream_t sm = G.s_main, sc = G.s_panel, sr = (G.tail_stream && G.s_rows) ? G.s_rows : G.s_main;
   const int nP = m->nP, np_ = m->Npad;
   const long ldk = m->ldk;
   hipEvent_t* ev_panel = m->ev.data();
@@ -603,7 +603,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
 
 // first outer panel of the tile-pipeline tail (nO: no tail): from there on every panel is a single 128-wide one
 static int tail_first_panel(const gpk_model* m) {
-  if (!G.tail_rows || !G.s_rows || m->P != 1) return m->nO;
+  if (!G.tail_rows || (G.tail_stream && !G.s_rows) || m->P != 1) return m->nO;
   int o = m->nO;
   while (o > 0 && m->ow[o - 1] == 128 && m->oend[o - 1] - m->ofirst[o - 1] == 1 && m->Npad - m->oc0[o - 1] <= G.tail_rows) --o;
   if (m->nO - o < 4) return m->nO;  // not worth a stream hand-over

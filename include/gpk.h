@@ -36,7 +36,9 @@ int         gpk_init(int device);            /* bind this process to a GPU  */
 void        gpk_shutdown(void);
 const char* gpk_last_error(void);
 int         gpk_sync(void);                  /* hipDeviceSynchronize        */
-int         gpk_set_option(const char* key, double value); /* "nb","lookahead",... */
+int         gpk_set_option(const char* key, double value); /* schedule switches: "nb", "lookahead", "gemm_pipe",
+                                                               "tail_rows", "leaf_server", ... (README.md); results do
+                                                               not depend on them beyond rounding, most not at all */
 double      gpk_get_option(const char* key);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */

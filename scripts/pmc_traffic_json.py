@@ -30,20 +30,33 @@ write_raw = sum(float(r["Counter_Value"]) for r in wr)
 n = len(fe)
 # algorithmic bytes: every lower 128x128 tile of C read + written once (16 B per element) + the panel read once;
 # exact algorithmic figures come from the panel schedule (same rule as gpk_core.hip model_create / potrf_device)
-N = 16384
-rem = N; c0 = 0; sched = []
-while c0 < N:
-    rem = N - c0
-    w = 512 if rem > 8192 + 512 else (128 if rem <= 2048 else 256)
-    sched.append((c0, w)); c0 += w
-alg_list = []
-for p, (c0, w) in enumerate(sched):
-    wn = sched[p + 1][1] if p + 1 < len(sched) else 0
-    m = N - c0 - w - wn
-    if m <= 0: continue
-    nt = m // 128
-    if nt * (nt + 1) // 2 < 256: continue          # small launches use the 64x64-tile kernel (small_tile_below)
-    alg_list.append((16.0 * 128 * 128 * nt * (nt + 1) / 2 + 8.0 * m * w, float(m) * m * w))
+def alg_model(N=16384, nb_big_until=8192, nb_small_from=4096, tail_rows=4096, small_tile_below=256):
+    """(bytes, flops) of every trailing-update launch of the 8-wave kernel in one factorisation, from the default panel
+    schedule (same rules as gpk_core.hip: model_create / potrf_device / potrf_tail)."""
+    c0 = 0; sched = []
+    while c0 < N:
+        rem = N - c0
+        w = 512 if rem > nb_big_until + 512 else (128 if rem <= nb_small_from else 256)
+        sched.append((c0, w)); c0 += w
+    tail = [i for i, (c, w) in enumerate(sched) if w == 128 and N - c <= tail_rows]
+    t0 = tail[0] if len(tail) >= 4 else len(sched)      # first panel of the tile pipeline
+    ms = []
+    for p, (c, w) in enumerate(sched):
+        if p < t0:
+            if p + 1 == t0: m = N - (c + w) - 384        # hand-over: three tile columns stay on the chain stream
+            else: m = N - c - w - (sched[p + 1][1] if p + 1 < len(sched) else 0)
+        else:
+            m = N - c - 512                              # REST(p) of the tile pipeline
+        ms.append((m, w))
+    out = []
+    for m, w in ms:
+        if m <= 0: continue
+        nt = m // 128
+        if nt * (nt + 1) // 2 < small_tile_below: continue   # small launches use the 64x64-tile kernel
+        out.append((16.0 * 128 * 128 * nt * (nt + 1) / 2 + 8.0 * m * w, float(m) * m * w))
+    return out
+
+alg_list = alg_model()
 out = {
     "kernel": "gemm_nt8_kernel (trailing-update launches of one factorisation on the update stream, N=16384)",
     "launches": n,

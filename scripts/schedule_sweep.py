@@ -32,6 +32,11 @@ if len(sys.argv) > 2 and sys.argv[2] == "tail":
     for t in (2048, 4096, 6144, 8192, 12288):
         configs.append(dict(tail_rows=t, nb_small_from=t))
     configs.append(dict(tail_rows=1 << 30, nb_small_from=1 << 30))
+elif len(sys.argv) > 2 and sys.argv[2] == "tail_main":  # the tile pipeline's full-height GEMMs on the update stream (three streams)
+    for t in (1024, 2048, 3072, 4096, 6144):
+        configs.append(dict(tail_stream=0, tail_rows=t, nb_small_from=t))
+    configs.append(dict(tail_stream=0, tail_rows=2048))
+    configs.append(dict(tail_stream=1, tail_rows=2048, nb_small_from=2048))
 elif len(sys.argv) > 2 and sys.argv[2] == "panels":
     for big, until in [(512, 4096), (512, 6144), (512, 12288), (1024, 8192), (1024, 4096), (768, 6144)]:
         for small_from in (2048, 4096):
@@ -54,7 +59,7 @@ else:
                 dict(nb_outer=1536, outer_until=4096, outer_from=8192),
                 dict(nb_outer=3072, outer_until=4096, outer_from=8192)]
 print("GPK_RESERVE_PER_XCD=%s GPU_MAX_HW_QUEUES=%s" % (os.environ.get("GPK_RESERVE_PER_XCD"), os.environ.get("GPU_MAX_HW_QUEUES")), flush=True)
-defaults = {k: _lib.get_option(k) for k in ("nb_outer", "outer_until", "outer_from", "nb_big_until", "nb_big", "tail_rows", "nb_small_from",
+defaults = {k: _lib.get_option(k) for k in ("nb_outer", "outer_until", "outer_from", "nb_big_until", "nb_big", "tail_rows", "tail_stream", "nb_small_from",
                                              "xcd_sq_min_tiles", "pair_update", "small_tile_below", "pred_small_below")}
 for cfg in configs:
     for k, v in defaults.items():

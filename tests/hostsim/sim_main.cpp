@@ -157,6 +157,11 @@ int main() {
   check_fit_predict(make_problem(900, 3, 20), "tile pipeline for the whole factorisation");
   CHECK(gpk_get_option("potrf_tail_from") == 0, "tile pipeline from panel 0");
   check_fit_predict(make_problem(300, 1, 5), "tile pipeline, three tiles");
+  opt("tail_rows", 0); opt("tail_stream", 0); opt("tail_rows", 1 << 30);  // the same with its full-height GEMMs on the update stream
+  check_fit_predict(make_problem(900, 3, 20), "tile pipeline on three streams");
+  CHECK(gpk_get_option("potrf_tail_from") == 0, "tile pipeline (three streams) from panel 0");
+  CHECK(gpk_set_option("tail_stream", 1) < 0, "tail_stream is refused while the pipeline is on");
+  opt("tail_rows", 0); opt("tail_stream", 1);
   opt("tail_rows", 0); opt("nb", 256); opt("nb_auto", 1);
   opt("nb_outer", 2048); opt("outer_from", 24576); opt("outer_until", 8192); opt("nb_big", 512); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
 

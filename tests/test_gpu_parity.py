@@ -234,14 +234,16 @@ def test_potrf_block_size_invariance(gpk, nb):
     (4096, {"nb_small_from": 4096, "tail_rows": 4096}, 0),                           # BASELINE config 2's size
 ])
 def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_from):
-    """potrf_tail (leaf + one-tile kernels on the chain stream, full-height panel GEMMs on a second stream, bulk on the
-    update stream) applies to every element the same rank-128 updates in the same order as the panel-level look-ahead
+    """potrf_tail (leaf + one-tile kernels on the chain stream, full-height panel GEMMs on a second stream or in front of
+    the bulk on the update stream, bulk on the update stream) applies to every element the same rank-128 updates in the same order as the panel-level look-ahead
     with the same 128-wide panels: the factors must agree bit for bit, and with NumPy's."""
     rng = np.random.RandomState(N)
     Q = rng.randn(N, N)
     A = Q @ Q.T + N * np.eye(N)
     out = []
-    for tail in (False, True):
+    for tail in (0, 1, 2):  # 0: panel level; 1: full-height GEMMs on a stream of their own; 2: on the update stream (option tail_stream = 0)
+        gpk.set_option("tail_rows", 0)
+        gpk.set_option("tail_stream", 0 if tail == 2 else 1)
         for k, v in opts.items():
             gpk.set_option(k, 0 if (k == "tail_rows" and not tail) else v)
         gpk.set_option("pair_update", 0)
@@ -254,6 +256,7 @@ def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_fro
             assert tf == -1
         out.append(L)
     np.testing.assert_array_equal(out[0], out[1])
+    np.testing.assert_array_equal(out[0], out[2])
     Lr = np.linalg.cholesky(A)
     np.testing.assert_allclose(out[1], Lr, rtol=1e-11, atol=1e-11 * np.abs(Lr).max())
     # not positive definite inside the tail: same LAPACK-style report
