@@ -254,6 +254,8 @@ int gpk_set_option(const char* key, double value) {
     G.xcd_sq = (int)value;
   } else if (k == "xcd_sq_min_tiles") {
     G.xcd_sq_min_tiles = (int)value;
+  } else if (k == "tt_fused") {
+    G.tt_fused = (int)value ? 1 : 0;
   } else if (k == "tail_stream") {
     if (G.tail_rows > 0) return gpk_set_err(-1, "option tail_stream must be set while tail_rows is 0");
     G.tail_stream = (int)value ? 1 : 0;
@@ -336,6 +338,7 @@ double gpk_get_option(const char* key) {
   if (k == "stamps") return G.stamps;
   if (k == "tail_rows") return G.tail_rows;
   if (k == "tail_stream") return G.tail_stream;
+  if (k == "tt_fused") return G.tt_fused;
   if (k == "potrf_tail_from") { extern int g_potrf_tail_from; return g_potrf_tail_from; }
   if (k == "test_gemm_k1") return G.test_gemm_k1;
   if (k == "leaf_algo") { extern int g_leaf_algo; return g_leaf_algo; }

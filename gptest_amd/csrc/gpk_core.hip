@@ -524,6 +524,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
   hipEvent_t* ev_near = m->ev.data() + 5 * nP + 6;
   hipEvent_t* ev_rest = m->ev.data() + 6 * nP + 6;
   GPK_HIP(hipStreamWaitEvent(sr, ev_prev_rest, 0));  // s_rows joins here; its first kernels also wait for a leaf
+  unsigned tt_count = 0;
   for (int p = p_first; p < nP; ++p) {
     const int c0 = m->pc0[p], h = np_ - c0;
     const long ld = m->pld[p];
@@ -541,13 +542,18 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       t1.B = Dt; t1.ldb = 128;
       t1.C = Lp + (long)128 * ld; t1.ldc = ld;
       t1.m = 128; t1.n = 128; t1.k = 128; t1.sub = 0;
-      GPK_TRY(launch_gemm_nt(t1, false, sc));
       GemmNT t2{};  // A(p+1,p+1) -= L(p+1,p) L(p+1,p)^T
       t2.A = Lp + (long)128 * ld; t2.lda = ld;
       t2.B = t2.A; t2.ldb = ld;
       t2.C = Acol + (long)128 * ldk + 128; t2.ldc = ldk;
       t2.m = 128; t2.n = 128; t2.k = 128; t2.sub = 1; t2.lower = 1;
-      GPK_TRY(launch_gemm_nt(t2, false, sc));
+      if (G.tt_fused) {  // both in one launch (dinfo[2] counts T1's blocks; zeroed with dinfo at the start of the factorisation)
+        tt_count += 4;
+        GPK_TRY(launch_tt_fused(t1, t2, reinterpret_cast<unsigned*>(m->dinfo + 2), tt_count, m->dinfo, sc));
+      } else {
+        GPK_TRY(launch_gemm_nt(t1, false, sc));
+        GPK_TRY(launch_gemm_nt(t2, false, sc));
+      }
       GPK_HIP(hipEventRecord(ev_tt[p], sc));
     }
     // ---- full-height panel GEMMs

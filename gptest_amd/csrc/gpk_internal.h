@@ -55,6 +55,9 @@ struct GemmNT {
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s);
 // the 8-wave kernel, with the XCD-aware tile order for the largest updates
 int launch_gemm_auto(const GemmNT& g, hipStream_t s);
+// T1 (one full 128x128 tile) and T2 (one lower 128x128 tile that reads T1's result) of a tile-pipeline step in one launch;
+// *ctr must have been `target - 4` when the launch starts (it counts T1's four blocks)
+int launch_tt_fused(const GemmNT& t1, const GemmNT& t2, unsigned* ctr, unsigned target, int* info, hipStream_t s);
 
 // ---------------------------------------------------------------- leaf factor
 // Factor the 128x128 diagonal tile A (lda) -> L tile (ldl, strict upper zeroed) and

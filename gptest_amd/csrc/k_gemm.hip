@@ -27,11 +27,11 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define BK 16
 #define LDS_LD (BK + 2)
 
+// One block tile of the 4-wave kernel (block `bid` of the launch described by g); lds: 2 * 2 * BT * LDS_LD doubles.
 template <int WT>  // MFMA tiles per wave per dimension: 4 -> 128x128 block, 2 -> 64x64 block
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
+static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int bid, double* lds) {
   constexpr int BT = 2 * WT * 16;       // block tile edge
   constexpr int PASSES = BT / 32;       // 32 rows of 16 doubles per pass with 256 threads
-  __shared__ double lds[2 * 2 * BT * LDS_LD];
   double* As = lds;                     // [2][BT][LDS_LD]
   double* Bs = lds + 2 * BT * LDS_LD;   // [2][BT][LDS_LD]
 
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
   const int ntn = g.n / BT;
   if (g.lower && g.cyc_P == 0) {
     // lower trapezoid (m >= n, C(0,0) on the diagonal): the n x n triangle first, then the full rows below it
-    int id = blockIdx.x;
+    int id = bid;
     const int tri = ntn * (ntn + 1) / 2;
     if (id < tri) {
       int t = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
       tj = id % ntn;
     }
   } else {
-    ti = blockIdx.x / ntn;
-    tj = blockIdx.x % ntn;
+    ti = bid / ntn;
+    tj = bid % ntn;
   }
   long brow0;  // first row of the B tile
   if (g.cyc_P > 0) {
@@ -147,6 +147,48 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
       for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + fg + 4 * r) * g.ldc + j * 16 + fr] = acc[i][j][r];
     }
   }
+}
+
+
+template <int WT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
+  __shared__ double lds[2 * 2 * (2 * WT * 16) * LDS_LD];
+  gemm_nt_body<WT>(g, (int)blockIdx.x, lds);
+}
+
+// The tile pipeline's two one-tile GEMMs of a chain step in ONE launch of four 64x64-tile workgroups: block b first does
+// block b of T1 (L21 = A21 Dinv^T, four blocks), publishes it (agent-scope fence, one count), and -- blocks 0..2 -- waits
+// until all four are counted before doing block b of T2 (the three lower blocks of A22 -= L21 L21^T).  Same tile code
+// as two launches, so the same bits; one dependent launch less on the chain.  `ctr` counts up over the steps of one
+// factorisation (launches are stream-ordered, so a step's blocks never see the next step's counts); the wait is bounded
+// (5 s of the 100 MHz clock), a time-out poisons *info like the leaf server does.
+__global__ __launch_bounds__(256, 2) void tt_fused_kernel(GemmNT t1, GemmNT t2, unsigned* ctr, unsigned target, int* info) {
+  __shared__ double lds[2 * 2 * 64 * LDS_LD];
+  __shared__ int gave_up;
+  const int b = (int)blockIdx.x;
+  gemm_nt_body<2>(t1, b, lds);
+  __threadfence();  // this block of L21 out of this XCD's L2 before it is counted
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int bad = 0;
+    if (b < 3) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > LEAF_SERVER_LIMIT_TICKS) { bad = 1; break; }
+      }
+    }
+    gave_up = bad;
+  }
+  __syncthreads();
+  if (b >= 3) return;
+  if (gave_up) {
+    if (threadIdx.x == 0 && info) atomicCAS(info, 0, LEAF_SERVER_INFO_POISON);
+    return;
+  }
+  __threadfence();  // the other blocks' L21 is read from memory, not from what this XCD's L2 may still hold
+  gemm_nt_body<2>(t2, b, lds);
 }
 
 int g_gemm_variant = 8;  // 8: 8-wave 128x128 kernel (default); 4: the 4-wave kernel
@@ -511,6 +553,15 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
       for (int r = 0; r < 4; ++r)
         __hip_atomic_store((Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16) + c_off, acc[i][j][r], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int launch_tt_fused(const GemmNT& t1, const GemmNT& t2, unsigned* ctr, unsigned target, int* info, hipStream_t s) {
+  if (t1.m != 128 || t1.n != 128 || t2.m != 128 || t2.n != 128 || t1.k % BK || t2.k % BK || t1.lower || !t2.lower || t1.cyc_P || t2.cyc_P ||
+      t1.k1 || t2.k1)
+    return gpk_set_err(-1, "tt_fused: one 128x128 tile each, T1 full, T2 lower");
+  hipLaunchKernelGGL(tt_fused_kernel, dim3(4), dim3(256), 0, s, t1, t2, ctr, target, info);
+  GPK_HIP(hipGetLastError());
+  return 0;
 }
 
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {

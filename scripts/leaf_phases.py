@@ -1,0 +1,11 @@
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gptest_amd import _lib
+_lib.init()
+l = _lib.lib()
+us = ctypes.c_double()
+for skip, what in [(0, "full leaf"), (1, "no elimination"), (2, "no inverse"), (3, "neither (load + stores only)"), (16, "no panel solve inside"), (32, "no trailing tile updates"), (64, "no diagonal blocks")]:
+    for rep in range(2):
+        l.gpk_bench_leaf(skip, 400, ctypes.byref(us))
+    print("dbg_skip=%2d %-32s %6.2f us per launch (back to back on one stream)" % (skip, what, us.value), flush=True)
+_lib.shutdown()

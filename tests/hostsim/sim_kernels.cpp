@@ -71,6 +71,13 @@ int launch_leaf_proxy(LeafMailbox* mb, unsigned seq, int op, const double* A, lo
   return launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, s);
 }
 
+int launch_tt_fused(const GemmNT& t1, const GemmNT& t2, unsigned* ctr, unsigned target, int*, hipStream_t s) {
+  if (!ctr || *ctr + 4 != target) return gpk_set_err(-1, "sim: fused T step out of sequence (counter %u, target %u)", ctr ? *ctr : 0u, target);
+  *ctr = target;
+  int rc = launch_gemm_nt(t1, false, s);
+  return rc ? rc : launch_gemm_nt(t2, false, s);
+}
+
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, int, hipStream_t) {
   static thread_local double t[128][128], inv[128][128];
   for (int i = 0; i < 128; ++i)
