@@ -1147,6 +1147,48 @@ int gpk_bench_mfma_pinned(int waves_per_simd, int iters, double* out) {
   return 0;
 }
 
+// A tile posted to the leaf server's mailbox while NO server is resident: the proxy must give up after its bounded wait
+// (LEAF_SERVER_LIMIT_TICKS = 5 s), raise the mailbox's error flag and poison *info.  Returns 0 when exactly that happened;
+// *seconds_out = how long the proxy waited.  (What a lost server -- or a server stream that shares a hardware queue with
+// the chain, GPU_MAX_HW_QUEUES too small -- looks like to the caller: an error, not a hang.)
+int gpk_test_leaf_server_timeout(double* seconds_out) {
+  GPK_TRY(rt_require());
+  if (G.leaf_chain) return gpk_set_err(-1, "gpk_test_leaf_server_timeout: a leaf session is open");
+  GPK_HIP(hipDeviceSynchronize());
+  if (!G.leaf_mb) {
+    GPK_HIP(hipMalloc((void**)&G.leaf_mb, sizeof(LeafMailbox)));
+    GPK_HIP(hipMemset(G.leaf_mb, 0, sizeof(LeafMailbox)));
+    G.leaf_seq = 1;
+  }
+  GPK_HIP(hipMemset(&G.leaf_mb->err, 0, 4));
+  Scratch sc;
+  int* dinfo = nullptr;
+  GPK_TRY(sc.get(&dinfo, 4));
+  GPK_HIP(hipMemset(dinfo, 0, 16));
+  hipEvent_t e0, e1;
+  GPK_HIP(hipEventCreate(&e0));
+  GPK_HIP(hipEventCreate(&e1));
+  GPK_HIP(hipEventRecord(e0, G.s_panel));
+  int rc = launch_leaf_proxy(G.leaf_mb, G.leaf_seq++, 0, nullptr, 0, nullptr, 0, nullptr, dinfo, 0, G.s_panel);
+  GPK_HIP(hipEventRecord(e1, G.s_panel));
+  GPK_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (seconds_out) *seconds_out = ms * 1e-3;
+  int hinfo = 0;
+  unsigned herr = 0;
+  GPK_HIP(hipMemcpy(&hinfo, dinfo, 4, hipMemcpyDeviceToHost));
+  GPK_HIP(hipMemcpy(&herr, &G.leaf_mb->err, 4, hipMemcpyDeviceToHost));
+  GPK_HIP(hipMemset(&G.leaf_mb->err, 0, 4));
+  if (rc) return rc;
+  if (hinfo != LEAF_SERVER_INFO_POISON || herr != 2u)
+    return gpk_set_err(-1, "leaf proxy without a server: info = %d (expected %d), mailbox error flag = %u (expected 2)", hinfo,
+                       LEAF_SERVER_INFO_POISON, herr);
+  return 0;
+}
+
 int gpk_bench_leaf(int dbg_skip, int reps, double* us_out) {
   GPK_TRY(rt_require());
   hipStream_t s = G.s_main;

@@ -203,6 +203,25 @@ def test_resident_leaf_server_is_bitwise_the_direct_leaf(gpk, N):
     assert gpk.lib().gpk_sync() == 0
 
 
+def test_leaf_server_waits_are_bounded(gpk):
+    """A tile posted to the mailbox with no server resident: the proxy gives up after its 5 s limit, flags the mailbox and
+    poisons *info -- an error for the caller, never a hang -- and the next factorisation through a server works."""
+    import ctypes
+
+    sec = ctypes.c_double()
+    assert gpk.lib().gpk_test_leaf_server_timeout(ctypes.byref(sec)) == 0, gpk.last_error()
+    assert 4.5 < sec.value < 8.0, sec.value
+    N = 900
+    rng = np.random.RandomState(3)
+    Q = rng.randn(N, 50)
+    A = Q @ Q.T + N * np.eye(N)
+    L0, L1 = A.copy(), A.copy()
+    assert gpk.lib().gpk_potrf(_ptr(L0), N) == 0, gpk.last_error()
+    gpk.set_option("leaf_server", 1)
+    assert gpk.lib().gpk_potrf(_ptr(L1), N) == 0, gpk.last_error()
+    assert np.array_equal(L0, L1)
+
+
 @pytest.mark.parametrize("N,bad", [(5, 3), (300, 131), (520, 519)])
 def test_potrf_not_positive_definite(gpk, N, bad):
     """LAPACK-style info > 0 -> the binding raises numpy.linalg.LinAlgError (what GPpref.py:133 catches)."""
