@@ -160,7 +160,9 @@ int main() {
   opt("tail_rows", 0); opt("tail_stream", 0); opt("tail_rows", 1 << 30);  // the same with its full-height GEMMs on the update stream
   check_fit_predict(make_problem(900, 3, 20), "tile pipeline on three streams");
   CHECK(gpk_get_option("potrf_tail_from") == 0, "tile pipeline (three streams) from panel 0");
-  CHECK(gpk_set_option("tail_stream", 1) < 0, "tail_stream is refused while the pipeline is on");
+  opt("tail_stream", 1);  // switching while the pipeline is on creates the stream ...
+  check_fit_predict(make_problem(700, 2, 9), "tile pipeline, stream switched on while active");
+  opt("tail_stream", 0);  // ... and drops it again
   opt("tail_rows", 0); opt("tail_stream", 1);
   opt("tail_rows", 0); opt("nb", 256); opt("nb_auto", 1);
   opt("nb_outer", 2048); opt("outer_from", 24576); opt("outer_until", 8192); opt("nb_big", 512); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
