@@ -254,6 +254,8 @@ int gpk_set_option(const char* key, double value) {
     G.xcd_sq = (int)value;
   } else if (k == "xcd_sq_min_tiles") {
     G.xcd_sq_min_tiles = (int)value;
+  } else if (k == "xcd_sorted") {
+    G.xcd_sorted = (int)value ? 1 : 0;
   } else if (k == "tt_fused") {
     G.tt_fused = (int)value ? 1 : 0;
   } else if (k == "tail_stream" || k == "tail_rows") {
@@ -340,6 +342,7 @@ double gpk_get_option(const char* key) {
   if (k == "tail_rows") return G.tail_rows;
   if (k == "tail_stream") return G.tail_stream;
   if (k == "tt_fused") return G.tt_fused;
+  if (k == "xcd_sorted") return G.xcd_sorted;
   if (k == "potrf_tail_from") { extern int g_potrf_tail_from; return g_potrf_tail_from; }
   if (k == "test_gemm_k1") return G.test_gemm_k1;
   if (k == "leaf_algo") { extern int g_leaf_algo; return g_leaf_algo; }
@@ -869,7 +872,7 @@ int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, 
   GemmNT g{};
   g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
   g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
-  g.xcd_sq = (G.xcd_sq == 2 && tile == 128) ? 1 : 0;  // option xcd_sq = 2: force the XCD-aware tile order (tests)
+  g.xcd_sq = (G.xcd_sq == 2 && tile == 128) ? (1 | (G.xcd_sorted ? 4 : 0)) : 0;  // option xcd_sq = 2: force the XCD-aware tile order (tests)
   const int k1 = G.test_gemm_k1;
   if (k1 > 0 && k1 < k) {
     // same product with the K range split over two separately stored operands (the paired trailing update);
@@ -1475,7 +1478,7 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
   GemmNT g{};
   g.A = dA; g.lda = k; g.B = lower ? dA : dB; g.ldb = k; g.C = dC; g.ldc = n;
   g.m = m; g.n = n; g.k = k; g.sub = 1; g.lower = lower & 1;
-  g.xcd_sq = G.xcd_sq;
+  g.xcd_sq = G.xcd_sq ? (G.xcd_sq | (G.xcd_sorted ? 4 : 0)) : 0;
   extern int g_gemm_variant;
   const int saved_variant = g_gemm_variant;
   if (tile == 4) g_gemm_variant = 4;

@@ -66,6 +66,7 @@ struct Runtime {
   int solve_gemm_above = 8;  // gpk_solve: more right-hand sides than this go through the blocked GEMM substitutions
   int fuse_predict = 1;  // bench / compute_prediction: overlap the prediction solve with the factorisation tail
   int xcd_sq = 1;              // XCD-aware 8x8-tile square order in the big GEMMs
+  int xcd_sorted = 0;          // ... with the squares of a round sorted by fill (full squares first, diagonal squares last)
   int xcd_sq_min_tiles = 8192; // ... for launches with at least this many 128x128 tiles in the bounding rectangle
   int ncu = 256;         // CUs available to the GEMM streams
   int small_tile_rows = 4096;  // GEMMs with n == 128 use the 64x64 tile below this many rows... (see potrf)

@@ -28,7 +28,7 @@ int rt_require() {
 int launch_gemm_auto(const GemmNT& g, hipStream_t s) {
   if (G.xcd_sq && g.cyc_P == 0 && g.m % 128 == 0 && g.n % 128 == 0 && (long)(g.m / 128) * (g.n / 128) >= G.xcd_sq_min_tiles) {
     GemmNT h = g;
-    h.xcd_sq = 1;
+    h.xcd_sq = 1 | (G.xcd_sorted ? 4 : 0);
     return launch_gemm_nt(h, true, s);
   }
   return launch_gemm_nt(g, true, s);

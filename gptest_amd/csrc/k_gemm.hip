@@ -238,7 +238,27 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     const int sq = (seq >> 6) * 8 + xcd, slot = seq & 63;
     const int SN = (ntn + 7) >> 3;
     int I, J;
-    if (g.lower) {  // lower trapezoid of squares: SN x SN triangle, then full rows of SN squares
+    if (g.lower && (g.xcd_sq & 4)) {
+      // sorted enumeration: the full squares first (the rows below the triangle, then the squares strictly below the
+      // diagonal), the half-empty diagonal squares last, so that the eight squares of a round (one per XCD) carry the
+      // same number of real tiles: workgroups are dispatched in index order, and an XCD that runs out of real work
+      // in its square while the next index belongs to a full XCD stalls everyone behind it.
+      const int SM = (ntm + 7) >> 3;
+      const int R = (SM - SN) * SN, F = SN * (SN - 1) / 2;
+      if (sq < R) {
+        I = SN + sq / SN;
+        J = sq % SN;
+      } else if (sq - R < F) {
+        const int q = sq - R;
+        int r = (int)((sqrtf(8.0f * (float)q + 1.0f) + 1.0f) * 0.5f);
+        while (r * (r - 1) / 2 > q) --r;
+        while ((r + 1) * r / 2 <= q) ++r;
+        I = r;
+        J = q - r * (r - 1) / 2;
+      } else {
+        I = J = sq - R - F;
+      }
+    } else if (g.lower) {  // lower trapezoid of squares: SN x SN triangle, then full rows of SN squares
       const int tri = SN * (SN + 1) / 2;
       if (sq < tri) {
         int r = (int)((sqrtf(8.0f * (float)sq + 1.0f) - 1.0f) * 0.5f);

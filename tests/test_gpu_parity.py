@@ -48,7 +48,8 @@ def test_mfma_gemm_nt(gpk, m, n, k, tile, sub, lower):
         np.testing.assert_allclose(C, ref, rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("m,n,k,tile", [(512, 256, 64, 128), (640, 128, 32, 64), (2304, 1152, 48, 128), (384, 384, 16, 64)])
+@pytest.mark.parametrize("m,n,k,tile", [(512, 256, 64, 128), (640, 128, 32, 64), (2304, 1152, 48, 128), (384, 384, 16, 64),
+                                        (2560, 2560, 16, 128), (3200, 2176, 16, 128), (1280, 1152, 32, 128)])
 def test_mfma_gemm_nt_lower_trapezoid(gpk, m, n, k, tile):
     """lower with m >= n: the n x n triangle of tiles plus the full rows below (the shape of an update restricted to
     a block column: look-ahead column, inner updates of the two-level schedule)."""
@@ -57,9 +58,10 @@ def test_mfma_gemm_nt_lower_trapezoid(gpk, m, n, k, tile):
     C0 = rng.randn(m, n)
     C = C0.copy()
     B = np.ascontiguousarray(A[:n])
-    for variant, xcd in ([(8, 1), (8, 2), (4, 1)] if tile == 128 else [(8, 1)]):
+    for variant, xcd, srt in ([(8, 1, 0), (8, 2, 0), (8, 2, 1), (4, 1, 0)] if tile == 128 else [(8, 1, 0)]):
         gpk.set_option("gemm_variant", variant)
         gpk.set_option("xcd_sq", xcd)   # 2: force the XCD-aware 8x8-square tile order of the big updates
+        gpk.set_option("xcd_sorted", srt)  # ... with the squares enumerated full ones first, diagonal ones last
         C[:] = C0
         assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, 1, tile) == 0, gpk.last_error()
         ref = C0 - A @ B.T
