@@ -223,6 +223,18 @@ def main():
         except Exception:
             pass
         flops = tr_flops / max(args.steps, 1)
+        # the chip's fp64 MFMA pipe re-measured on THIS box after the timed region: an issue loop of
+        # v_mfma_f64_16x16x4_f64 with exactly 4 waves pinned on every SIMD (gpk_bench_mfma_pinned), about 30 ms
+        peak_measured = None
+        if world == 1:
+            try:
+                pm = (ctypes.c_double * 6)()
+                if l.gpk_bench_mfma_pinned(4, 200000, pm) == 0:
+                    peak_measured = {"tflops": pm[0], "shader_clock_ghz": pm[1], "frac_of_it": (ach / pm[0]) if pm[0] else None,
+                                     "note": "v_mfma_f64_16x16x4_f64 issue loop, 4 waves pinned per SIMD on all 256 CUs (unmasked stream), "
+                                             "run after the timed region; the trailing update itself runs on a CU-masked stream (248 CUs)"}
+            except Exception:
+                pass
         out = {
             "metric": "GP posterior solves/sec (N=%d, d=%d, M=%d; fit + predict sharing one Cholesky)" % (N, d, M),
             "value": args.steps / (t_ms * 1e-3),
@@ -243,7 +255,8 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "block-cyclic panels x%d, RCCL broadcast" % world},
             "roofline": {"kernel": "gemm_nt8_kernel (Cholesky trailing update, fp64 MFMA 16x16x4)", "bound": "mfma",
                          "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                         "frac": ach / PEAK_FP64_MFMA_TFLOPS, "peak_measured": peak_measured,
+                         "traffic": traffic, "traffic_note": traffic_note,
                          "mfma_pmc_serialised": mfma_pmc,
                          "launches": tr_n, "avg_launch_ms": tr_ms / tr_n if tr_n else None,
                          "alg_flops_per_step_in_timed_launches": flops},
