@@ -77,6 +77,7 @@ def _bind(l):
         "gpk_bench_mfma_peak2": (i, [i, i, i, dp]),
         "gpk_bench_mfma_pinned": (i, [i, i, dp]),
         "gpk_test_leaf_server_timeout": (i, [dp]),
+        "gpk_bench_lds_bank_probe": (i, [i, i]),
         "gpk_bench_leaf": (i, [i, i, dp]),
         "gpk_bench_leaf_contended": (i, [i, dp, dp]),
         "gpk_bench_chain_step": (i, [i, i, i, dp, dp]),

@@ -1151,6 +1151,57 @@ int gpk_bench_mfma_pinned(int waves_per_simd, int iters, double* out) {
   return 0;
 }
 
+}  // extern "C"
+
+// LDS banking probe: every lane issues `reps` ds_read_b64 from one fixed address given by `pattern`; run under
+// `rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE` (scripts/lds_bank_probe.sh).  fr = lane & 15, fg = lane >> 4 as in
+// the MFMA operand layout.  0: lane * 8 (contiguous); 1: the LDS-DMA image of the tile kernel (128-byte rows, 16-byte chunks
+// XOR-swizzled by (row >> 1) & 7, k = fg); 2: rows 18 doubles apart (the register-staged image); 3: rows 17 doubles apart;
+// 4: 128-byte rows with an 8-byte swizzle ((fr & 7) * 2 + ((fr >> 3) ^ (fg & 1))); 5: pattern 1 without the swizzle.
+template <int PAT>
+__global__ __launch_bounds__(256) void lds_bank_probe_kernel(double* out, int reps) {
+  __shared__ double buf[64 * 18 + 64];
+  for (int e = threadIdx.x; e < 64 * 18 + 64; e += 256) buf[e] = (double)e;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
+  int idx;
+  if (PAT == 0) idx = lane;
+  else if (PAT == 1) idx = fr * 16 + ((((fg >> 1) ^ ((fr >> 1) & 7)) * 2) + (fg & 1));
+  else if (PAT == 2) idx = fr * 18 + fg;
+  else if (PAT == 3) idx = fr * 17 + fg;
+  else if (PAT == 4) idx = fr * 16 + (((fr & 7) * 2 + ((fr >> 3) ^ (fg & 1))) ^ ((fg >> 1) * 2)) % 16;
+  else idx = fr * 16 + fg;
+  const double* p = buf + idx;
+  double acc = 0;
+  for (int r = 0; r < reps; ++r) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(unsigned long)(__attribute__((address_space(3))) const double*)p) : "memory");
+    acc += v;
+  }
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+extern "C" {
+
+int gpk_bench_lds_bank_probe(int pattern, int reps) {
+  GPK_TRY(rt_require());
+  Scratch sc;
+  double* d = nullptr;
+  GPK_TRY(sc.get(&d, (size_t)256 * 256));
+  hipStream_t s = G.s_main;
+  switch (pattern) {
+    case 0: hipLaunchKernelGGL(lds_bank_probe_kernel<0>, dim3(256), dim3(256), 0, s, d, reps); break;
+    case 1: hipLaunchKernelGGL(lds_bank_probe_kernel<1>, dim3(256), dim3(256), 0, s, d, reps); break;
+    case 2: hipLaunchKernelGGL(lds_bank_probe_kernel<2>, dim3(256), dim3(256), 0, s, d, reps); break;
+    case 3: hipLaunchKernelGGL(lds_bank_probe_kernel<3>, dim3(256), dim3(256), 0, s, d, reps); break;
+    case 4: hipLaunchKernelGGL(lds_bank_probe_kernel<4>, dim3(256), dim3(256), 0, s, d, reps); break;
+    default: hipLaunchKernelGGL(lds_bank_probe_kernel<5>, dim3(256), dim3(256), 0, s, d, reps); break;
+  }
+  GPK_HIP(hipGetLastError());
+  GPK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 // A tile posted to the leaf server's mailbox while NO server is resident: the proxy must give up after its bounded wait
 // (LEAF_SERVER_LIMIT_TICKS = 5 s), raise the mailbox's error flag and poison *info.  Returns 0 when exactly that happened;
 // *seconds_out = how long the proxy waited.  (What a lost server -- or a server stream that shares a hardware queue with

@@ -14,8 +14,10 @@
 //   * A/B fragment: lane l holds M[r0 + (l&15)][k0 + (l>>4)]  (both operands are
 //     k-contiguous, so A and B use the same LDS image and the same read).
 //   * C/D fragment (f64 only!): col = lane&15, row = (lane>>4) + 4*reg.
-//   * LDS row stride BK+2 doubles: the 32 lanes of a ds_read_b64 group touch
-//     dword banks 36*r + 2*g (+0,1) mod 64 -> all 64 banks once: conflict-free.
+//   * LDS row stride BK+2 doubles (register-staged forms): the 32 lanes of a ds_read_b64 group touch
+//     dword banks 36*r + 2*g (+0,1) mod 64 -> all 64 banks once.  (The compiler merges pairs of those reads into
+//     ds_read2_b64, which is banked mod 32 and half rate: measured 2-way conflicts, scripts/pmc_lds.sh.  The
+//     LDS-DMA form issues its ds_read_b64 by inline asm and measures conflict-free.)
 //   * 2 workgroups per CU (64 KiB of LDS each in the LDS-DMA form, 72 KiB register-staged) so one
 //     workgroup's C tile hand-over overlaps the other's MFMA main loop.
 #include "gpk_internal.h"
@@ -404,14 +406,35 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
       const int k = 4 * q + fg;
       koff[q] = ((k >> 1) ^ fsw) * 2 + (k & 1);
     }
-    const double* Ab0 = lds + (wm * 64 + fr) * BK;
-    const double* Bb0 = lds + OPD + (wn * 32 + fr) * BK;
+    // Fragment reads as single ds_read_b64 by inline asm: left to the compiler, pairs of them are merged into
+    // ds_read2st64_b64, which is banked mod 32 in 16-lane groups and half rate -- 16 LDS-array cycles per instruction with
+    // a 2-way conflict under this swizzle instead of 2 conflict-free cycles per ds_read_b64 (scripts/lds_bank_probe.sh,
+    // scripts/pmc_lds.sh: SQ_LDS_BANK_CONFLICT 50 % of SQ_LDS_IDX_ACTIVE before, 0 after).  hipcc does not count asm
+    // loads, so the waits are explicit: LDS returns in order, `lgkmcnt(6)` retires the older of two fragment sets.
+    unsigned adA[4], adB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      adA[q] = lds0 + (unsigned)(((wm * 64 + fr) * BK + koff[q]) * 8);
+      adB[q] = lds0 + (unsigned)((OPD + (wn * 32 + fr) * BK + koff[q]) * 8);
+    }
     double pa[2][4], pb[2][2];
+#define GPK_DSR(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     auto rd = [&](int slot, int buf, int q) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pa[slot][i] = Ab0[buf * STG + i * 16 * BK + koff[q]];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) pb[slot][j] = Bb0[buf * STG + j * 16 * BK + koff[q]];
+      const unsigned a = adA[q] + (unsigned)buf * (STG * 8), b = adB[q] + (unsigned)buf * (STG * 8);
+      GPK_DSR(pa[slot][0], a, 0 * 16 * BK * 8);
+      GPK_DSR(pa[slot][1], a, 1 * 16 * BK * 8);
+      GPK_DSR(pa[slot][2], a, 2 * 16 * BK * 8);
+      GPK_DSR(pa[slot][3], a, 3 * 16 * BK * 8);
+      GPK_DSR(pb[slot][0], b, 0 * 16 * BK * 8);
+      GPK_DSR(pb[slot][1], b, 1 * 16 * BK * 8);
+    };
+#undef GPK_DSR
+    // the fragment set `slot` is in registers once at most `newer` younger LDS reads are outstanding
+    auto landed6 = [&](int slot) {
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(pa[slot][0]), "+v"(pa[slot][1]), "+v"(pa[slot][2]), "+v"(pa[slot][3]), "+v"(pb[slot][0]), "+v"(pb[slot][1]));
+    };
+    auto landed0 = [&](int slot) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pa[slot][0]), "+v"(pa[slot][1]), "+v"(pa[slot][2]), "+v"(pa[slot][3]), "+v"(pb[slot][0]), "+v"(pb[slot][1]));
     };
     {
       constexpr int NEGA = NEG ? 1 : 0;  // the host instantiates NEG = (sub != 0)
@@ -431,21 +454,22 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
         const int buf = kt & 1;
         __builtin_amdgcn_sched_barrier(0);
         rd(1, buf, 1);
+        landed6(0);
         __builtin_amdgcn_sched_barrier(0);
         mm(0);
         __builtin_amdgcn_sched_barrier(0);
         rd(0, buf, 2);
+        landed6(1);
         __builtin_amdgcn_sched_barrier(0);
         mm(1);
         __builtin_amdgcn_sched_barrier(0);
         rd(1, buf, 3);
+        landed6(0);
         __builtin_amdgcn_sched_barrier(0);
         mm(0);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pa[1][i]));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(pb[1][j]));
+        // the last fragments of this slab IN REGISTERS before the barrier releases its buffer
+        landed0(1);
         // B_kt: every wave's DMA of slab kt+1 (issued a slab ago) has landed, this slab's buffer is released
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(DBG & 2)) __syncthreads();

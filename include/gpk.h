@@ -180,6 +180,8 @@ int gpk_bench_chain_step(int reps, int nsmall, int small_m, double* us_alone, do
 int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_out);
 /* device-resident timing of the MFMA GEMM: C (m x n) -= A (m x k) B (n x k)^T, `reps` launches; ms per launch. */
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out);
+/* LDS banking probe for rocprofv3 --pmc (scripts/lds_bank_probe.sh): `reps` ds_read_b64 per lane in one of six address patterns. */
+int gpk_bench_lds_bank_probe(int pattern, int reps);
 /* the leaf server's bounded wait: a tile posted with no server resident must come back as an error after ~5 s (0 = it did). */
 int gpk_test_leaf_server_timeout(double* seconds_out);
 /* leaf kernel timing; dbg_skip bit0 = skip elimination, bit1 = skip inverse (timing only). */
