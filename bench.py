@@ -224,12 +224,12 @@ def main():
             pass
         flops = tr_flops / max(args.steps, 1)
         # the chip's fp64 MFMA pipe re-measured on THIS box after the timed region: an issue loop of
-        # v_mfma_f64_16x16x4_f64 with exactly 4 waves pinned on every SIMD (gpk_bench_mfma_pinned), about 30 ms
+        # v_mfma_f64_16x16x4_f64 with exactly 4 waves pinned on every SIMD (gpk_bench_mfma_pinned), about 10 ms
         peak_measured = None
         if world == 1:
             try:
                 pm = (ctypes.c_double * 6)()
-                if l.gpk_bench_mfma_pinned(4, 200000, pm) == 0:
+                if l.gpk_bench_mfma_pinned(4, 60000, pm) == 0:
                     peak_measured = {"tflops": pm[0], "shader_clock_ghz": pm[1], "frac_of_it": (ach / pm[0]) if pm[0] else None,
                                      "note": "v_mfma_f64_16x16x4_f64 issue loop, 4 waves pinned per SIMD on all 256 CUs (unmasked stream), "
                                              "run after the timed region; the trailing update itself runs on a CU-masked stream (248 CUs)"}
