@@ -124,6 +124,31 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
     if (kt + 1 < nk) gload(kt + 1);
     const double* Ab = As + (buf * BT + wm * WT * 16 + fr) * LDS_LD + fg;
     const double* Bb = Bs + (buf * BT + wn * WT * 16 + fr) * LDS_LD + fg;
+    if constexpr (WT == 2) {
+      // one wave per SIMD and workgroup: the fragments of k-step s+1 are read under the MFMAs of k-step s (same MFMA
+      // order, same bits), so that one LDS latency per slab is exposed instead of four
+      double a[2][WT], b[2][WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) a[0][i] = Ab[i * 16 * LDS_LD];
+#pragma unroll
+      for (int j = 0; j < WT; ++j) b[0][j] = Bb[j * 16 * LDS_LD];
+#pragma unroll
+      for (int q = 0; q < BK / 4; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < BK / 4) {
+#pragma unroll
+          for (int i = 0; i < WT; ++i) a[(q + 1) & 1][i] = Ab[i * 16 * LDS_LD + 4 * (q + 1)];
+#pragma unroll
+          for (int j = 0; j < WT; ++j) b[(q + 1) & 1][j] = Bb[j * 16 * LDS_LD + 4 * (q + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+          for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q & 1][i], b[q & 1][j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
       double a[WT], b[WT];
@@ -135,6 +160,7 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
       for (int i = 0; i < WT; ++i)
 #pragma unroll
         for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
     }
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
