@@ -22,14 +22,6 @@ def trailing(rows):
     per_step = len(g) // 3            # warmup 1 + steps 2
     return g[-per_step:]
 
-fe = trailing(load(sys.argv[1], "FETCH_SIZE"))
-wr = trailing(load(sys.argv[2], "WRITE_SIZE"))
-assert len(fe) == len(wr) and len(fe) > 0, (len(fe), len(wr))
-fetch_raw = sum(float(r["Counter_Value"]) for r in fe)
-write_raw = sum(float(r["Counter_Value"]) for r in wr)
-n = len(fe)
-# algorithmic bytes: every lower 128x128 tile of C read + written once (16 B per element) + the panel read once;
-# exact algorithmic figures come from the panel schedule (same rule as gpk_core.hip model_create / potrf_device)
 def alg_model(N=16384, nb_big_until=8192, nb_small_from=4096, tail_rows=4096, small_tile_below=256):
     """(bytes, flops) of every trailing-update launch of the 8-wave kernel in one factorisation, from the default panel
     schedule (same rules as gpk_core.hip: model_create / potrf_device / potrf_tail)."""
@@ -56,20 +48,34 @@ def alg_model(N=16384, nb_big_until=8192, nb_small_from=4096, tail_rows=4096, sm
         out.append((16.0 * 128 * 128 * nt * (nt + 1) / 2 + 8.0 * m * w, float(m) * m * w))
     return out
 
-alg_list = alg_model()
-out = {
-    "kernel": "gemm_nt8_kernel (trailing-update launches of one factorisation on the update stream, N=16384)",
-    "launches": n,
-    "launches_expected_from_schedule": len(alg_list),
-    "fetch_size_kb_raw": fetch_raw,
-    "write_size_kb_raw": write_raw,
-    "fetch_bytes_corrected_x2": fetch_raw * 1024.0 * 2.0,
-    "write_bytes": write_raw * 1024.0,
-    "hbm_bytes_per_launch": (fetch_raw * 1024.0 * 2.0 + write_raw * 1024.0) / n,
-    "algorithmic_bytes_per_launch": sum(a for a, _ in alg_list) / max(1, len(alg_list)),
-    "algorithmic_flops_per_launch": sum(f for _, f in alg_list) / max(1, len(alg_list)),
-    "note": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --steps 2 --warmup 1`; counters in KiB; "
-            "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); algorithmic = 16 B per element of the lower C tiles (read + written once) "
-            "+ 8*m*w (panel read once)",
-}
-print(json.dumps(out, indent=1))
+
+def main():
+    fe = trailing(load(sys.argv[1], "FETCH_SIZE"))
+    wr = trailing(load(sys.argv[2], "WRITE_SIZE"))
+    assert len(fe) == len(wr) and len(fe) > 0, (len(fe), len(wr))
+    fetch_raw = sum(float(r["Counter_Value"]) for r in fe)
+    write_raw = sum(float(r["Counter_Value"]) for r in wr)
+    n = len(fe)
+    # algorithmic bytes: every lower 128x128 tile of C read + written once (16 B per element) + the panel read once;
+    # exact algorithmic figures come from the panel schedule (same rule as gpk_core.hip model_create / potrf_device)
+    alg_list = alg_model()
+    out = {
+        "kernel": "gemm_nt8_kernel (trailing-update launches of one factorisation on the update stream, N=16384)",
+        "launches": n,
+        "launches_expected_from_schedule": len(alg_list),
+        "fetch_size_kb_raw": fetch_raw,
+        "write_size_kb_raw": write_raw,
+        "fetch_bytes_corrected_x2": fetch_raw * 1024.0 * 2.0,
+        "write_bytes": write_raw * 1024.0,
+        "hbm_bytes_per_launch": (fetch_raw * 1024.0 * 2.0 + write_raw * 1024.0) / n,
+        "algorithmic_bytes_per_launch": sum(a for a, _ in alg_list) / max(1, len(alg_list)),
+        "algorithmic_flops_per_launch": sum(f for _, f in alg_list) / max(1, len(alg_list)),
+        "note": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --steps 2 --warmup 1`; counters in KiB; "
+                "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); algorithmic = 16 B per element of the lower C tiles (read + written once) "
+                "+ 8*m*w (panel read once)",
+    }
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

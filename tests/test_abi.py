@@ -71,3 +71,26 @@ def test_gpr_surface_matches_reference_names():
     # unknown names silently give [] exactly like GPr.py:31-42
     gp2 = GPr.GaussianProcess(lh, 0, 0, "XX", "YY", "ZZ", x, y)
     assert gp2.covFun == [] and gp2.meanFun == [] and gp2.likeFun == []
+
+
+def test_traffic_model_matches_the_committed_bench_line():
+    """scripts/pmc_traffic_json.py restates the default panel schedule to price the algorithmic bytes of the trailing
+    launches; its flop total must be the one bench.py measured from the library's own launch accounting (the committed
+    bench line), or the traffic ratio in DESIGN.md compares two different sets of launches."""
+    import importlib.util
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pmc_traffic_json", os.path.join(root, "scripts", "pmc_traffic_json.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    model = mod.alg_model()
+    with open(os.path.join(root, "profiles", "r02_bench_line.json")) as fh:
+        line = json.loads(fh.read())
+    r = line["roofline"]
+    assert len(model) * line["steps"] == r["launches"]
+    assert sum(f for _, f in model) == r["alg_flops_per_step_in_timed_launches"]
+    with open(os.path.join(root, "profiles", "r02_traffic_gemm_nt8.json")) as fh:
+        tj = json.load(fh)
+    assert tj["launches"] == len(model) == tj["launches_expected_from_schedule"]
