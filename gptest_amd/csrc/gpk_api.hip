@@ -256,6 +256,8 @@ int gpk_set_option(const char* key, double value) {
     G.xcd_sq_min_tiles = (int)value;
   } else if (k == "xcd_sorted") {
     G.xcd_sorted = (int)value ? 1 : 0;
+  } else if (k == "tail_leaf_event") {
+    G.tail_leaf_event = (int)value ? 1 : 0;
   } else if (k == "tt_fused") {
     G.tt_fused = (int)value ? 1 : 0;
   } else if (k == "tail_stream" || k == "tail_rows") {
@@ -342,6 +344,7 @@ double gpk_get_option(const char* key) {
   if (k == "tail_rows") return G.tail_rows;
   if (k == "tail_stream") return G.tail_stream;
   if (k == "tt_fused") return G.tt_fused;
+  if (k == "tail_leaf_event") return G.tail_leaf_event;
   if (k == "xcd_sorted") return G.xcd_sorted;
   if (k == "potrf_tail_from") { extern int g_potrf_tail_from; return g_potrf_tail_from; }
   if (k == "test_gemm_k1") return G.test_gemm_k1;

@@ -532,9 +532,13 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
     double* Acol = m->dK + (long)c0 * ldk + c0;
     double* Dt = m->dDinv + (long)(c0 / 128) * 128 * 128;
     hipEvent_t rest_before = (p > p_first) ? ev_rest[p - 1] : ev_prev_rest;
-    // ---- critical stream
+    // ---- critical stream.  One event per step: `tt` after the two one-tile GEMMs (or `leaf` for the last tile, which has
+    // none).  The full-height solve only needs the leaf, but it waits for `tt` as well: an event packet on the chain
+    // stream costs ~5 us of a ~85 us step, and the solve is never what the chain waits for next (near(p) is due one
+    // leaf later).  G.tail_leaf_event = 1 restores the separate leaf event.
+    const bool leaf_ev = G.tail_leaf_event || h <= 128;
     GPK_TRY(leaf_launch(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, sc));
-    GPK_HIP(hipEventRecord(ev_leaf[p], sc));
+    if (leaf_ev) GPK_HIP(hipEventRecord(ev_leaf[p], sc));
     if (h > 128) {
       if (p > p_first) GPK_HIP(hipStreamWaitEvent(sc, ev_near[p - 1], 0));
       GemmNT t1{};  // L(p+1,p) = A(p+1,p) Dinv^T
@@ -557,7 +561,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       GPK_HIP(hipEventRecord(ev_tt[p], sc));
     }
     // ---- full-height panel GEMMs
-    GPK_HIP(hipStreamWaitEvent(sr, ev_leaf[p], 0));
+    GPK_HIP(hipStreamWaitEvent(sr, leaf_ev ? ev_leaf[p] : ev_tt[p], 0));
     if (h > 256) {
       GemmNT g{};  // SOLVE(p): rows from tile p+2
       g.A = Acol + (long)256 * ldk; g.lda = ldk;
@@ -566,7 +570,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       g.m = h - 256; g.n = 128; g.k = 128; g.sub = 0;
       GPK_TRY(launch_gemm_nt(g, false, sr));
     }
-    if (h > 128) GPK_HIP(hipStreamWaitEvent(sr, ev_tt[p], 0));
+    if (h > 128 && leaf_ev) GPK_HIP(hipStreamWaitEvent(sr, ev_tt[p], 0));
     GPK_HIP(hipEventRecord(ev_panel[p], sr));  // every row of panel p is in place
     if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sr));
     if (after_panel) GPK_TRY((*after_panel)(p));
