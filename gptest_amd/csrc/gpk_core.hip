@@ -584,7 +584,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
     }
     GPK_HIP(hipEventRecord(ev_near[p], sr));
     if (h > 384) {
-      GPK_HIP(hipStreamWaitEvent(sr, rest_before, 0));
+      if (sr != sm) GPK_HIP(hipStreamWaitEvent(sr, rest_before, 0));  // (same stream: stream order; an event packet costs ~5 us)
       GemmNT g{};  // LAfar(p): tile column p+3, rows from tile p+3
       g.A = Lp + (long)384 * ld; g.lda = ld;
       g.B = g.A; g.ldb = ld;
@@ -593,7 +593,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       GPK_TRY(launch_gemm_nt(g, false, sr));
     }
     // ---- bulk
-    GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
+    if (sr != sm) GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
     if (h > 512) {
       const int r1 = c0 + 512;
       const long nt = (np_ - r1) / 128;
@@ -602,7 +602,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       GPK_TRY(panel_update(m, p, r1, r1, np_ - r1, 1, sm));
       timer_end(tname, sm);
     }
-    GPK_HIP(hipEventRecord(ev_rest[p], sm));
+    if (sr != sm) GPK_HIP(hipEventRecord(ev_rest[p], sm));
   }
   // join: everything after potrf runs on s_main
   GPK_HIP(hipStreamWaitEvent(sm, ev_panel[nP - 1], 0));
