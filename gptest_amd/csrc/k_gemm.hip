@@ -30,7 +30,10 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define LDS_LD (BK + 2)
 
 // One block tile of the 4-wave kernel (block `bid` of the launch described by g); lds: 2 * 2 * BT * LDS_LD doubles.
-template <int WT>  // MFMA tiles per wave per dimension: 4 -> 128x128 block, 2 -> 64x64 block
+// COH (the fused T step of the tile pipeline): 1 = C is stored THROUGH the caches (agent-scope stores), 2 = the A / B
+// operands are read PAST them (agent-scope loads), so that blocks of one launch can hand a tile to each other
+// without writing back or invalidating a whole L2.
+template <int WT, int COH = 0>  // MFMA tiles per wave per dimension: 4 -> 128x128 block, 2 -> 64x64 block
 static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int bid, double* lds) {
   constexpr int BT = 2 * WT * 16;       // block tile edge
   constexpr int PASSES = BT / 32;       // 32 rows of 16 doubles per pass with 256 threads
@@ -84,8 +87,15 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
   auto gload = [&](int kt) {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      ra[p] = *reinterpret_cast<const d2*>(Ag + (long)(p * 32 + lrow) * g.lda + kt * BK + lchk);
-      rb[p] = *reinterpret_cast<const d2*>(Bg + (long)(p * 32 + lrow) * g.ldb + kt * BK + lchk);
+      const double* pa_ = Ag + (long)(p * 32 + lrow) * g.lda + kt * BK + lchk;
+      const double* pb_ = Bg + (long)(p * 32 + lrow) * g.ldb + kt * BK + lchk;
+      if (COH == 2) {
+        ra[p] = (d2){__hip_atomic_load(pa_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(pa_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+        rb[p] = (d2){__hip_atomic_load(pb_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(pb_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+      } else {
+        ra[p] = *reinterpret_cast<const d2*>(pa_);
+        rb[p] = *reinterpret_cast<const d2*>(pb_);
+      }
     }
   };
   // sub mode, exactly as in the 8-wave kernel below (so that every kernel of this file rounds identically and the
@@ -172,7 +182,11 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
 #pragma unroll
     for (int j = 0; j < WT; ++j) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + fg + 4 * r) * g.ldc + j * 16 + fr] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) {
+        double* pc_ = Cg + (long)(i * 16 + fg + 4 * r) * g.ldc + j * 16 + fr;
+        if (COH == 1) __hip_atomic_store(pc_, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *pc_ = acc[i][j][r];
+      }
     }
   }
 }
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 }
 
 // The tile pipeline's two one-tile GEMMs of a chain step in ONE launch of four 64x64-tile workgroups: block b first does
-// block b of T1 (L21 = A21 Dinv^T, four blocks), publishes it (agent-scope fence, one count), and -- blocks 0..2 -- waits
+// block b of T1 (L21 = A21 Dinv^T, four blocks), publishes it (stores through the caches, one count), and -- blocks 0..2 -- waits
 // until all four are counted before doing block b of T2 (the three lower blocks of A22 -= L21 L21^T).  Same tile code
 // as two launches, so the same bits; one dependent launch less on the chain.  `ctr` counts up over the steps of one
 // factorisation (launches are stream-ordered, so a step's blocks never see the next step's counts); the wait is bounded
@@ -194,8 +208,8 @@ __global__ __launch_bounds__(256, 2) void tt_fused_kernel(GemmNT t1, GemmNT t2, 
   __shared__ double lds[2 * 2 * 64 * LDS_LD];
   __shared__ int gave_up;
   const int b = (int)blockIdx.x;
-  gemm_nt_body<2>(t1, b, lds);
-  __threadfence();  // this block of L21 out of this XCD's L2 before it is counted
+  gemm_nt_body<2, 1>(t1, b, lds);  // L21 written through the caches
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and out of this wave before the block is counted
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -215,8 +229,7 @@ __global__ __launch_bounds__(256, 2) void tt_fused_kernel(GemmNT t1, GemmNT t2, 
     if (threadIdx.x == 0 && info) atomicCAS(info, 0, LEAF_SERVER_INFO_POISON);
     return;
   }
-  __threadfence();  // the other blocks' L21 is read from memory, not from what this XCD's L2 may still hold
-  gemm_nt_body<2>(t2, b, lds);
+  gemm_nt_body<2, 2>(t2, b, lds);  // the other blocks' L21 is read past the caches (this XCD's L2 may hold last posterior's)
 }
 
 int g_gemm_variant = 8;  // 8: 8-wave 128x128 kernel (default); 4: the 4-wave kernel
