@@ -607,7 +607,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
   // join: everything after potrf runs on s_main
   GPK_HIP(hipStreamWaitEvent(sm, ev_panel[nP - 1], 0));
   GPK_HIP(hipStreamWaitEvent(sm, ev_near[nP - 1], 0));
-  if (nP - 1 > p_first || true) GPK_HIP(hipStreamWaitEvent(sm, ev_leaf[nP - 1], 0));
+  GPK_HIP(hipStreamWaitEvent(sm, ev_leaf[nP - 1], 0));  // the last tile has no T step: its leaf event is always recorded
   return 0;
 }
 
