@@ -191,6 +191,8 @@ void gpk_shutdown(void) {
   G.leaf_chain = nullptr;
   if (G.leaf_mb) (void)hipFree(G.leaf_mb);
   G.leaf_mb = nullptr;
+  if (G.dflags) (void)hipFree(G.dflags);
+  G.dflags = nullptr;
   SD_STEP("destroy s_rows", if (G.s_rows) (void)hipStreamDestroy(G.s_rows));
   SD_STEP("destroy s_comm", if (G.s_comm) (void)hipStreamDestroy(G.s_comm));
   G.s_comm = nullptr;
@@ -256,6 +258,8 @@ int gpk_set_option(const char* key, double value) {
     G.xcd_sq_min_tiles = (int)value;
   } else if (k == "xcd_sorted") {
     G.xcd_sorted = (int)value ? 1 : 0;
+  } else if (k == "tail_flags") {
+    G.tail_flags = (int)value ? 1 : 0;
   } else if (k == "tail_leaf_event") {
     G.tail_leaf_event = (int)value ? 1 : 0;
   } else if (k == "tt_fused") {
@@ -345,6 +349,7 @@ double gpk_get_option(const char* key) {
   if (k == "tail_stream") return G.tail_stream;
   if (k == "tt_fused") return G.tt_fused;
   if (k == "tail_leaf_event") return G.tail_leaf_event;
+  if (k == "tail_flags") return G.tail_flags;
   if (k == "xcd_sorted") return G.xcd_sorted;
   if (k == "potrf_tail_from") { extern int g_potrf_tail_from; return g_potrf_tail_from; }
   if (k == "test_gemm_k1") return G.test_gemm_k1;

@@ -51,6 +51,8 @@ struct Runtime {
   // tile pipeline (potrf_tail) for the chain-bound last tail_rows columns (needs 128-wide panels there: nb_small_from);
   // 0 = the panel-level look-ahead everywhere
   int tail_rows = 4096;
+  int tail_flags = 0;       // tile pipeline: flag-chained steps (leaf kernels on the chain stream, T kernels on the update stream, flags in HBM)
+  unsigned* dflags = nullptr;  // 4 words per tile step (leaf flag, tt flag, two counters), zeroed at the start of a factorisation
   int tail_leaf_event = 0;  // tile pipeline: 1 = a separate event after every leaf (the full-height solve then starts ~20 us earlier)
   int tt_fused = 0;     // tile pipeline: the chain's two one-tile GEMMs of a step in ONE launch (k_gemm.hip: tt_fused_kernel); measured: no gain, off
   int tail_stream = 0;  // the tile pipeline's full-height GEMMs: 0 in front of the bulk on the update stream (default), 1 on a stream of their own (s_rows, a FOURTH stream)

@@ -525,6 +525,11 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
   hipEvent_t* ev_rest = m->ev.data() + 6 * nP + 6;
   GPK_HIP(hipStreamWaitEvent(sr, ev_prev_rest, 0));  // s_rows joins here; its first kernels also wait for a leaf
   unsigned tt_count = 0;
+  const bool flags = G.tail_flags && sr == sm && G.dflags && nP <= 1024;
+  if (flags) {  // the caller's look-ahead work on the chain stream precedes the first T step, which now runs on the update stream
+    GPK_HIP(hipEventRecord(ev_tt[p_first], sc));
+    GPK_HIP(hipStreamWaitEvent(sm, ev_tt[p_first], 0));
+  }
   for (int p = p_first; p < nP; ++p) {
     const int c0 = m->pc0[p], h = np_ - c0;
     const long ld = m->pld[p];
@@ -537,10 +542,20 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
     // stream costs ~5 us of a ~85 us step, and the solve is never what the chain waits for next (near(p) is due one
     // leaf later).  G.tail_leaf_event = 1 restores the separate leaf event.
     const bool leaf_ev = G.tail_leaf_event || h <= 128;
+    if (flags) {
+      // FLAG-CHAINED step (option tail_flags): the chain stream carries nothing but leaf kernels, each of which spins until
+      // the previous step's T kernel has set its flag; that T kernel sits on the update stream -- behind LAnear(p-1), which
+      // it needs, by stream order -- and spins until its leaf has set the leaf flag.  No event packet, no dependent launch
+      // on the chain (k_gemm.hip: tt_flag_kernel, k_potf2.hip: leaf_flag_kernel; every wait bounded).
+      unsigned* F = G.dflags + 4 * (size_t)p;  // leaf flag, tt flag, two counters (zeroed with dinfo)
+      GPK_TRY(launch_leaf_flag(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, p > p_first ? F - 4 + 1 : nullptr, F, sc));
+      if (h <= 128) GPK_HIP(hipEventRecord(ev_leaf[p], sc));
+    } else {
     GPK_TRY(leaf_launch(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, sc));
     if (leaf_ev) GPK_HIP(hipEventRecord(ev_leaf[p], sc));
+    }
     if (h > 128) {
-      if (p > p_first) GPK_HIP(hipStreamWaitEvent(sc, ev_near[p - 1], 0));
+      if (p > p_first && !flags) GPK_HIP(hipStreamWaitEvent(sc, ev_near[p - 1], 0));
       GemmNT t1{};  // L(p+1,p) = A(p+1,p) Dinv^T
       t1.A = Acol + (long)128 * ldk; t1.lda = ldk;
       t1.B = Dt; t1.ldb = 128;
@@ -551,17 +566,20 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       t2.B = t2.A; t2.ldb = ld;
       t2.C = Acol + (long)128 * ldk + 128; t2.ldc = ldk;
       t2.m = 128; t2.n = 128; t2.k = 128; t2.sub = 1; t2.lower = 1;
-      if (G.tt_fused) {  // both in one launch (dinfo[2] counts T1's blocks; zeroed with dinfo at the start of the factorisation)
+      if (flags) {
+        unsigned* F = G.dflags + 4 * (size_t)p;
+        GPK_TRY(launch_tt_flag(t1, t2, F, F + 2, F + 1, m->dinfo, sm));
+      } else if (G.tt_fused) {  // both in one launch (dinfo[2] counts T1's blocks; zeroed with dinfo at the start of the factorisation)
         tt_count += 4;
         GPK_TRY(launch_tt_fused(t1, t2, reinterpret_cast<unsigned*>(m->dinfo + 2), tt_count, m->dinfo, sc));
       } else {
         GPK_TRY(launch_gemm_nt(t1, false, sc));
         GPK_TRY(launch_gemm_nt(t2, false, sc));
       }
-      GPK_HIP(hipEventRecord(ev_tt[p], sc));
+      if (!flags) GPK_HIP(hipEventRecord(ev_tt[p], sc));
     }
     // ---- full-height panel GEMMs
-    GPK_HIP(hipStreamWaitEvent(sr, leaf_ev ? ev_leaf[p] : ev_tt[p], 0));
+    if (!flags || h <= 128) GPK_HIP(hipStreamWaitEvent(sr, leaf_ev ? ev_leaf[p] : ev_tt[p], 0));
     if (h > 256) {
       GemmNT g{};  // SOLVE(p): rows from tile p+2
       g.A = Acol + (long)256 * ldk; g.lda = ldk;
@@ -570,7 +588,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       g.m = h - 256; g.n = 128; g.k = 128; g.sub = 0;
       GPK_TRY(launch_gemm_nt(g, false, sr));
     }
-    if (h > 128 && leaf_ev) GPK_HIP(hipStreamWaitEvent(sr, ev_tt[p], 0));
+    if (h > 128 && leaf_ev && !flags) GPK_HIP(hipStreamWaitEvent(sr, ev_tt[p], 0));
     GPK_HIP(hipEventRecord(ev_panel[p], sr));  // every row of panel p is in place
     if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sr));
     if (after_panel) GPK_TRY((*after_panel)(p));
@@ -631,6 +649,13 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
     return potrf_group(&one, 1);
   }
   GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
+  if (G.tail_flags) {
+    if (!G.dflags && hipMalloc((void**)&G.dflags, 4 * 1024 * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      G.dflags = nullptr;
+    }
+    if (G.dflags) GPK_HIP(hipMemsetAsync(G.dflags, 0, 4 * 1024 * sizeof(unsigned), sm));
+  }
   const int nP = m->nP;
   g_potrf_lookahead_used = 0;
   if (!G.lookahead || nP < 3) {

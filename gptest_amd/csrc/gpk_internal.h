@@ -58,6 +58,11 @@ int launch_gemm_auto(const GemmNT& g, hipStream_t s);
 // T1 (one full 128x128 tile) and T2 (one lower 128x128 tile that reads T1's result) of a tile-pipeline step in one launch;
 // *ctr must have been `target - 4` when the launch starts (it counts T1's four blocks)
 int launch_tt_fused(const GemmNT& t1, const GemmNT& t2, unsigned* ctr, unsigned target, int* info, hipStream_t s);
+// flag-chained tile pipeline (potrf_tail, option tail_flags): the T step launched on the update stream ahead of its leaf,
+// and the leaf kernel that waits for the previous T step's flag.  ctr2: two zeroed words, flags: zeroed words.
+int launch_tt_flag(const GemmNT& t1, const GemmNT& t2, const unsigned* leaf_flag, unsigned* ctr2, unsigned* tt_flag, int* info, hipStream_t s);
+int launch_leaf_flag(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, const unsigned* wait_flag,
+                     unsigned* set_flag, hipStream_t s);
 
 // ---------------------------------------------------------------- leaf factor
 // Factor the 128x128 diagonal tile A (lda) -> L tile (ldl, strict upper zeroed) and

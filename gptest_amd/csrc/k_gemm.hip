@@ -30,9 +30,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define LDS_LD (BK + 2)
 
 // One block tile of the 4-wave kernel (block `bid` of the launch described by g); lds: 2 * 2 * BT * LDS_LD doubles.
-// COH (the fused T step of the tile pipeline): 1 = C is stored THROUGH the caches (agent-scope stores), 2 = the A / B
-// operands are read PAST them (agent-scope loads), so that blocks of one launch can hand a tile to each other
-// without writing back or invalidating a whole L2.
+// COH (the fused / flag-chained T step of the tile pipeline), a bit mask: 1 = C is stored THROUGH the caches (agent-scope
+// stores), 2 = the A / B operands are read PAST them (agent-scope loads), so that concurrently running workgroups and
+// kernels can hand a tile to each other without writing back or invalidating a whole L2.
 template <int WT, int COH = 0>  // MFMA tiles per wave per dimension: 4 -> 128x128 block, 2 -> 64x64 block
 static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int bid, double* lds) {
   constexpr int BT = 2 * WT * 16;       // block tile edge
@@ -89,7 +89,7 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
     for (int p = 0; p < PASSES; ++p) {
       const double* pa_ = Ag + (long)(p * 32 + lrow) * g.lda + kt * BK + lchk;
       const double* pb_ = Bg + (long)(p * 32 + lrow) * g.ldb + kt * BK + lchk;
-      if (COH == 2) {
+      if (COH & 2) {
         ra[p] = (d2){__hip_atomic_load(pa_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(pa_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
         rb[p] = (d2){__hip_atomic_load(pb_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(pb_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
       } else {
@@ -184,7 +184,7 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double* pc_ = Cg + (long)(i * 16 + fg + 4 * r) * g.ldc + j * 16 + fr;
-        if (COH == 1) __hip_atomic_store(pc_, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (COH & 1) __hip_atomic_store(pc_, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *pc_ = acc[i][j][r];
       }
     }
@@ -636,6 +636,62 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
       for (int r = 0; r < 4; ++r)
         __hip_atomic_store((Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16) + c_off, acc[i][j][r], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The T step of the FLAG-CHAINED tile pipeline (potrf_tail, option tail_flags): launched on the update stream AHEAD of
+// the leaf it depends on, its four workgroups spin (bounded) until the leaf kernel on the chain stream has set
+// `leaf_flag`, do T1 (operands past the caches: Dinv comes from a kernel that is still running elsewhere; result through
+// them), count, do T2 (blocks 0..2; operands past, result through the caches: the next leaf reads it past them), and the
+// last T2 block to finish sets `tt_flag`, which is what the next leaf kernel waits for.  No event packet and no dependent
+// launch is left on the chain: ~58 instead of ~85 us per 128 columns.  ctr[0] counts T1 blocks, ctr[1] T2 blocks.
+__global__ __launch_bounds__(256, 2) void tt_flag_kernel(GemmNT t1, GemmNT t2, const unsigned* leaf_flag, unsigned* ctr, unsigned* tt_flag,
+                                                         int* info) {
+  __shared__ double lds[2 * 2 * 64 * LDS_LD];
+  __shared__ int gave_up;
+  const int b = (int)blockIdx.x;
+  if (threadIdx.x == 0) {
+    int bad = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(leaf_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > LEAF_SERVER_LIMIT_TICKS) { bad = 1; break; }
+    }
+    gave_up = bad;
+  }
+  __syncthreads();
+  if (gave_up && threadIdx.x == 0 && info) atomicCAS(info, 0, LEAF_SERVER_INFO_POISON);  // (and go on: the followers must not wait as well)
+  gemm_nt_body<2, 3>(t1, b, lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int bad = 0;
+    if (b < 3) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > LEAF_SERVER_LIMIT_TICKS) { bad = 1; break; }
+      }
+    }
+    gave_up = bad;
+  }
+  __syncthreads();
+  if (b >= 3) return;
+  if (gave_up && threadIdx.x == 0 && info) atomicCAS(info, 0, LEAF_SERVER_INFO_POISON);
+  gemm_nt_body<2, 3>(t2, b, lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u)
+    __hip_atomic_store(tt_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int launch_tt_flag(const GemmNT& t1, const GemmNT& t2, const unsigned* leaf_flag, unsigned* ctr2, unsigned* tt_flag, int* info, hipStream_t s) {
+  if (t1.m != 128 || t1.n != 128 || t2.m != 128 || t2.n != 128 || t1.k % BK || t2.k % BK || t1.lower || !t2.lower || t1.cyc_P || t2.cyc_P ||
+      t1.k1 || t2.k1 || !leaf_flag || !ctr2 || !tt_flag)
+    return gpk_set_err(-1, "tt_flag: one 128x128 tile each, T1 full, T2 lower, three flag words");
+  hipLaunchKernelGGL(tt_flag_kernel, dim3(4), dim3(256), 0, s, t1, t2, leaf_flag, ctr2, tt_flag, info);
+  GPK_HIP(hipGetLastError());
+  return 0;
 }
 
 int launch_tt_fused(const GemmNT& t1, const GemmNT& t2, unsigned* ctr, unsigned target, int* info, hipStream_t s) {

@@ -501,6 +501,45 @@ __global__ __launch_bounds__(64) void leaf_proxy_kernel(LeafMailbox* mb, unsigne
   if (!ok && info) atomicCAS(info, 0, LEAF_SERVER_INFO_POISON);
 }
 
+// The leaf of the FLAG-CHAINED tile pipeline: waits (bounded) for `wait_flag` -- set by the previous step's T kernel on the
+// update stream; nullptr for the first tile -- factors its tile with cache-bypassing accesses (the tile was written by that
+// still-running kernel through the caches), and sets `set_flag` when L and Dinv are out.
+template <int ALGO>
+__global__ __launch_bounds__(1024) void leaf_flag_kernel(const double* __restrict__ A, long lda, double* __restrict__ L, long ldl,
+                                                         double* __restrict__ Dinv, int* info, int col0, const unsigned* wait_flag,
+                                                         unsigned* set_flag) {
+  __shared__ __attribute__((aligned(16))) double S[128 * PLD + 2 * CBLD + 128];
+  __shared__ double rinvb[16];
+  __shared__ int failflag;
+  __shared__ int gave_up;
+  const int tid = threadIdx.x;
+  if (wait_flag) {
+    if (tid == 0) {
+      int bad = 0;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (mb_load(wait_flag) == 0u) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > LEAF_SERVER_LIMIT_TICKS) { bad = 1; break; }
+      }
+      gave_up = bad;
+    }
+    __syncthreads();
+    if (gave_up && tid == 0 && info) atomicCAS(info, 0, LEAF_SERVER_INFO_POISON);
+  }
+  leaf_body<ALGO, true>(A, lda, L, ldl, Dinv, info, col0, 0, S, rinvb, failflag, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0 && set_flag) mb_store(set_flag, 1u);
+}
+
+int launch_leaf_flag(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, const unsigned* wait_flag,
+                     unsigned* set_flag, hipStream_t s) {
+  if (g_leaf_algo == 0) hipLaunchKernelGGL(leaf_flag_kernel<0>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, wait_flag, set_flag);
+  else hipLaunchKernelGGL(leaf_flag_kernel<1>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, wait_flag, set_flag);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_leaf_server(LeafMailbox* mb, unsigned first_seq, hipStream_t s) {
   static_assert(offsetof(LeafMailbox, go) == 128 && offsetof(LeafMailbox, done) == 256 && offsetof(LeafMailbox, err) == 384,
                 "mailbox layout");

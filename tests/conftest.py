@@ -32,7 +32,7 @@ def golden_cases():
 # comes after it)
 OPTION_KEYS = ["nb", "nb_auto", "nb_big", "nb_big_until", "nb_small", "nb_small_from", "nb_outer", "outer_from",
                "outer_until", "lookahead", "dist_group", "ldk_pad", "pred_gate_rows", "gemm_variant",
-               "xcd_sq", "xcd_sorted", "xcd_sq_min_tiles", "tail_rows", "tail_stream", "tt_fused", "tail_leaf_event", "stamps", "pred_small_below", "small_tile_below", "leaf_algo",
+               "xcd_sq", "xcd_sorted", "xcd_sq_min_tiles", "tail_rows", "tail_stream", "tt_fused", "tail_leaf_event", "tail_flags", "stamps", "pred_small_below", "small_tile_below", "leaf_algo",
                "test_gemm_k1", "pair_update", "leaf_server", "gemm_pipe", "pipe_interleave", "fuse_predict", "solve_gemm_above", "timing"]
 
 

@@ -71,6 +71,24 @@ int launch_leaf_proxy(LeafMailbox* mb, unsigned seq, int op, const double* A, lo
   return launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, s);
 }
 
+// flag-chained tile pipeline on the CPU: every "kernel" runs at once in host order, so a flag must already be set when its
+// waiter is "launched" -- which is exactly the enqueue-order property the device version relies on for freedom from deadlock
+int launch_leaf_flag(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, const unsigned* wait_flag,
+                     unsigned* set_flag, hipStream_t s) {
+  if (wait_flag && *wait_flag == 0) return gpk_set_err(-1, "sim: leaf enqueued before the T step it waits for");
+  int rc = launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, s);
+  if (set_flag) *set_flag = 1;
+  return rc;
+}
+int launch_tt_flag(const GemmNT& t1, const GemmNT& t2, const unsigned* leaf_flag, unsigned* ctr2, unsigned* tt_flag, int*, hipStream_t s) {
+  if (!leaf_flag || *leaf_flag == 0) return gpk_set_err(-1, "sim: T step enqueued before its leaf");
+  if (ctr2[0] || ctr2[1] || *tt_flag) return gpk_set_err(-1, "sim: T step flags not zeroed");
+  int rc = launch_gemm_nt(t1, false, s);
+  if (!rc) rc = launch_gemm_nt(t2, false, s);
+  ctr2[0] = 4; ctr2[1] = 3; *tt_flag = 1;
+  return rc;
+}
+
 int launch_tt_fused(const GemmNT& t1, const GemmNT& t2, unsigned* ctr, unsigned target, int*, hipStream_t s) {
   if (!ctr || *ctr + 4 != target) return gpk_set_err(-1, "sim: fused T step out of sequence (counter %u, target %u)", ctr ? *ctr : 0u, target);
   *ctr = target;

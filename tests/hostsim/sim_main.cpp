@@ -160,6 +160,9 @@ int main() {
   opt("tail_rows", 0); opt("tail_stream", 0); opt("tail_rows", 1 << 30);  // the same with its full-height GEMMs on the update stream
   check_fit_predict(make_problem(900, 3, 20), "tile pipeline on three streams");
   CHECK(gpk_get_option("potrf_tail_from") == 0, "tile pipeline (three streams) from panel 0");
+  opt("tail_flags", 1);  // flag-chained steps: the stand-ins check that every flag is set before its waiter is enqueued
+  check_fit_predict(make_problem(1000, 3, 20), "tile pipeline, flag-chained");
+  opt("tail_flags", 0);
   opt("tail_stream", 1);  // switching while the pipeline is on creates the stream ...
   check_fit_predict(make_problem(700, 2, 9), "tile pipeline, stream switched on while active");
   opt("tail_stream", 0);  // ... and drops it again

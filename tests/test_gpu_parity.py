@@ -262,11 +262,12 @@ def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_fro
     Q = rng.randn(N, N)
     A = Q @ Q.T + N * np.eye(N)
     out = []
-    for tail in (0, 1, 2, 3, 4):  # 0: panel level; 1: full-height GEMMs on a stream of their own; 2: on the update stream (option tail_stream = 0); 3: ... and the chain's two one-tile GEMMs as two launches (tt_fused = 0); 4: ... with a separate event after every leaf
+    for tail in (0, 1, 2, 3, 4, 5):  # 5: flag-chained steps (option tail_flags); 0: panel level; 1: full-height GEMMs on a stream of their own; 2: on the update stream (option tail_stream = 0); 3: ... and the chain's two one-tile GEMMs as two launches (tt_fused = 0); 4: ... with a separate event after every leaf
         gpk.set_option("tail_rows", 0)
         gpk.set_option("tail_stream", 1 if tail == 1 else 0)
         gpk.set_option("tt_fused", 1 if tail in (1, 2) else 0)
         gpk.set_option("tail_leaf_event", 1 if tail == 4 else 0)
+        gpk.set_option("tail_flags", 1 if tail == 5 else 0)
         for k, v in opts.items():
             gpk.set_option(k, 0 if (k == "tail_rows" and not tail) else v)
         gpk.set_option("pair_update", 0)
@@ -282,6 +283,7 @@ def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_fro
     np.testing.assert_array_equal(out[0], out[2])
     np.testing.assert_array_equal(out[0], out[3])
     np.testing.assert_array_equal(out[0], out[4])
+    np.testing.assert_array_equal(out[0], out[5])
     Lr = np.linalg.cholesky(A)
     np.testing.assert_allclose(out[1], Lr, rtol=1e-11, atol=1e-11 * np.abs(Lr).max())
     # not positive definite inside the tail: same LAPACK-style report
