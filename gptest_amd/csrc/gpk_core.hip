@@ -530,6 +530,34 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
     GPK_HIP(hipEventRecord(ev_tt[p_first], sc));
     GPK_HIP(hipStreamWaitEvent(sm, ev_tt[p_first], 0));
   }
+  // flag-chained mode: leaf kernel of step q on the chain stream and its T kernel on the update stream.  They are queued
+  // right behind LAnear(q-1) -- all the T step needs from the update stream -- and IN FRONT of LAfar(q-1) / REST(q-1), so
+  // that the T kernel is resident and spinning when its leaf ends instead of queueing behind a step's worth of launches.
+  auto enqueue_flag_step = [&](int q) -> int {
+    const int qc0 = m->pc0[q], qh = np_ - qc0;
+    const long qld = m->pld[q];
+    double* qLp = m->Lpanel(q);
+    double* qA = m->dK + (long)qc0 * ldk + qc0;
+    double* qD = m->dDinv + (long)(qc0 / 128) * 128 * 128;
+    unsigned* F = G.dflags + 4 * (size_t)q;  // leaf flag, tt flag, two counters (zeroed with dinfo)
+    GPK_TRY(launch_leaf_flag(qA, ldk, qLp, qld, qD, m->dinfo, qc0, q > p_first ? F - 4 + 1 : nullptr, F, sc));
+    if (qh <= 128) {
+      GPK_HIP(hipEventRecord(ev_leaf[q], sc));
+      return 0;
+    }
+    GemmNT t1{};  // L(q+1,q) = A(q+1,q) Dinv^T
+    t1.A = qA + (long)128 * ldk; t1.lda = ldk;
+    t1.B = qD; t1.ldb = 128;
+    t1.C = qLp + (long)128 * qld; t1.ldc = qld;
+    t1.m = 128; t1.n = 128; t1.k = 128; t1.sub = 0;
+    GemmNT t2{};  // A(q+1,q+1) -= L(q+1,q) L(q+1,q)^T
+    t2.A = qLp + (long)128 * qld; t2.lda = qld;
+    t2.B = t2.A; t2.ldb = qld;
+    t2.C = qA + (long)128 * ldk + 128; t2.ldc = ldk;
+    t2.m = 128; t2.n = 128; t2.k = 128; t2.sub = 1; t2.lower = 1;
+    return launch_tt_flag(t1, t2, F, F + 2, F + 1, m->dinfo, sm);
+  };
+  if (flags) GPK_TRY(enqueue_flag_step(p_first));
   for (int p = p_first; p < nP; ++p) {
     const int c0 = m->pc0[p], h = np_ - c0;
     const long ld = m->pld[p];
@@ -542,20 +570,17 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
     // stream costs ~5 us of a ~85 us step, and the solve is never what the chain waits for next (near(p) is due one
     // leaf later).  G.tail_leaf_event = 1 restores the separate leaf event.
     const bool leaf_ev = G.tail_leaf_event || h <= 128;
-    if (flags) {
-      // FLAG-CHAINED step (option tail_flags): the chain stream carries nothing but leaf kernels, each of which spins until
-      // the previous step's T kernel has set its flag; that T kernel sits on the update stream -- behind LAnear(p-1), which
-      // it needs, by stream order -- and spins until its leaf has set the leaf flag.  No event packet, no dependent launch
-      // on the chain (k_gemm.hip: tt_flag_kernel, k_potf2.hip: leaf_flag_kernel; every wait bounded).
-      unsigned* F = G.dflags + 4 * (size_t)p;  // leaf flag, tt flag, two counters (zeroed with dinfo)
-      GPK_TRY(launch_leaf_flag(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, p > p_first ? F - 4 + 1 : nullptr, F, sc));
-      if (h <= 128) GPK_HIP(hipEventRecord(ev_leaf[p], sc));
-    } else {
+    // FLAG-CHAINED steps (option tail_flags): the chain stream carries nothing but leaf kernels, each of which spins until
+    // the previous step's T kernel has set its flag; that T kernel sits on the update stream -- behind LAnear(p-1), which
+    // it needs, by stream order -- and spins until its leaf has set the leaf flag.  No event packet, no dependent launch
+    // on the chain (k_gemm.hip: tt_flag_kernel, k_potf2.hip: leaf_flag_kernel; every wait bounded).  Step p's pair was
+    // queued by enqueue_flag_step (before the loop, or behind LAnear(p-1) below).
+    if (!flags) {
     GPK_TRY(leaf_launch(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, sc));
     if (leaf_ev) GPK_HIP(hipEventRecord(ev_leaf[p], sc));
     }
-    if (h > 128) {
-      if (p > p_first && !flags) GPK_HIP(hipStreamWaitEvent(sc, ev_near[p - 1], 0));
+    if (h > 128 && !flags) {
+      if (p > p_first) GPK_HIP(hipStreamWaitEvent(sc, ev_near[p - 1], 0));
       GemmNT t1{};  // L(p+1,p) = A(p+1,p) Dinv^T
       t1.A = Acol + (long)128 * ldk; t1.lda = ldk;
       t1.B = Dt; t1.ldb = 128;
@@ -566,17 +591,14 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       t2.B = t2.A; t2.ldb = ld;
       t2.C = Acol + (long)128 * ldk + 128; t2.ldc = ldk;
       t2.m = 128; t2.n = 128; t2.k = 128; t2.sub = 1; t2.lower = 1;
-      if (flags) {
-        unsigned* F = G.dflags + 4 * (size_t)p;
-        GPK_TRY(launch_tt_flag(t1, t2, F, F + 2, F + 1, m->dinfo, sm));
-      } else if (G.tt_fused) {  // both in one launch (dinfo[2] counts T1's blocks; zeroed with dinfo at the start of the factorisation)
+      if (G.tt_fused) {  // both in one launch (dinfo[2] counts T1's blocks; zeroed with dinfo at the start of the factorisation)
         tt_count += 4;
         GPK_TRY(launch_tt_fused(t1, t2, reinterpret_cast<unsigned*>(m->dinfo + 2), tt_count, m->dinfo, sc));
       } else {
         GPK_TRY(launch_gemm_nt(t1, false, sc));
         GPK_TRY(launch_gemm_nt(t2, false, sc));
       }
-      if (!flags) GPK_HIP(hipEventRecord(ev_tt[p], sc));
+      GPK_HIP(hipEventRecord(ev_tt[p], sc));
     }
     // ---- full-height panel GEMMs
     if (!flags || h <= 128) GPK_HIP(hipStreamWaitEvent(sr, leaf_ev ? ev_leaf[p] : ev_tt[p], 0));
@@ -601,6 +623,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       GPK_TRY(launch_gemm_nt(g, false, sr));
     }
     GPK_HIP(hipEventRecord(ev_near[p], sr));
+    if (flags && p + 1 < nP) GPK_TRY(enqueue_flag_step(p + 1));
     if (h > 384) {
       if (sr != sm) GPK_HIP(hipStreamWaitEvent(sr, rest_before, 0));  // (same stream: stream order; an event packet costs ~5 us)
       GemmNT g{};  // LAfar(p): tile column p+3, rows from tile p+3
