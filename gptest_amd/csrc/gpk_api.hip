@@ -1,6 +1,7 @@
 // extern "C" surface of libgpk.so (see include/gpk.h for the contract and the
 // reference file:line each entry point replaces).
 #include "../../include/gpk.h"
+#include "../../include/gpk_testhooks.h"
 #include "gpk_core.h"
 #include <cmath>
 #include <map>
@@ -440,6 +441,8 @@ static int model_unpack_L(gpk_model* m, double* L_out_host) {
 
 int gpk_potrf(double* A, int N) {
   if (!A) return gpk_set_err(-1, "gpk_potrf: null pointer");
+  GPK_TRY(rt_require());
+  if (G.nranks > 1) return gpk_set_err(-1, "gpk_potrf: a caller-owned matrix is factored on one GPU (this process is rank %d of %d)", G.rank, G.nranks);
   gpk_model* m = nullptr;
   GPK_TRY(model_create(&m, N, 1, false));
   hipStream_t s = G.s_main;
@@ -468,6 +471,7 @@ int gpk_fit(const double* X, const double* y, int N, int d, const double* log_hy
   if ((flags & 2) && !(flags & 1)) return gpk_set_err(-1, "gpk_fit: flag 2 (K only, no factorisation) needs flag 1 (keep K)");
   if ((flags & 2) && y) return gpk_set_err(-1, "gpk_fit: flag 2 (K only) takes no targets");
   if ((flags & 4) && (flags & 3)) return gpk_set_err(-1, "gpk_fit: flag 4 (growable) cannot be combined with keep-K / K-only");
+  if ((flags & 4) && G.nranks > 1) return gpk_set_err(-1, "gpk_fit: growable models are single-GPU only");
   gpk_model* m = nullptr;
   GPK_TRY(model_create(&m, N, d, (flags & 1) != 0, -1, -1, (flags & 4) != 0));
   m->k_only = (flags & 2) != 0;

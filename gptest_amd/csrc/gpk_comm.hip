@@ -3,6 +3,7 @@
 // The reference has no distributed code at all; this is the exchange step that
 // BASELINE.json's north_star prescribes (panel broadcast over xGMI).
 #include "../../include/gpk.h"
+#include "../../include/gpk_testhooks.h"
 #include "gpk_core.h"
 #include <rccl/rccl.h>
 #include <cstring>

@@ -1053,13 +1053,16 @@ int fit_group(gpk_model* const* ms, int n) {
     GPK_HIP(hipMemcpyAsync(&hinfo[i], ms[i]->dinfo, 4, hipMemcpyDeviceToHost, s));
   }
   GPK_HIP(hipStreamSynchronize(s));
-  // only the owner of the failing panel saw the pivot: the verdict is the maximum over all ranks
+  // Only the owner of the failing panel saw the pivot, and once one tile has failed the owners of later panels fail as
+  // well (on what the identity factors of the failed tile left them): the verdict is the FIRST failing minor over all
+  // ranks, as LAPACK reports it -- the smallest positive info, found with the max-reduction as the largest 2^30 - info.
   int worst = 0;
-  for (int i = 0; i < n; ++i) worst = std::max(worst, hinfo[i]);
+  for (int i = 0; i < n; ++i)
+    if (hinfo[i] > 0 && (worst == 0 || hinfo[i] < worst)) worst = hinfo[i];
   if (!ms[0]->virtual_rank && ms[0]->P > 1) {
-    double hi = (double)worst;
+    double hi = worst > 0 ? (double)((1 << 30) - worst) : 0.0;
     GPK_TRY(gpk_comm_allreduce_max(&hi, 1));
-    worst = (int)hi;
+    worst = hi > 0.0 ? (1 << 30) - (int)hi : 0;
   }
   for (int i = 0; i < n; ++i) {
     gpk_model* m = ms[i];

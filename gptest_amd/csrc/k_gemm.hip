@@ -261,7 +261,9 @@ static __device__ __forceinline__ void glds16(const double* sbase, unsigned voff
 template <bool TWOSEG, int DBG = 0, bool PIPE = false, bool GLDS = false, bool NEG = false>  // TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update)
 __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   constexpr int BT = 128;
-  __shared__ double lds[2 * 2 * BT * LDS_LD];
+  // LDS-DMA form: the unpadded image, exactly 64 KiB -- two workgroups per CU leave 32 KiB, and ONE finished workgroup
+  // frees a 96 KiB slot, which is what the slot-sized leaf (k_potf2.hip) is built to fit
+  __shared__ double lds[2 * 2 * BT * (GLDS ? BK : LDS_LD)];
   double* As = lds;
   double* Bs = lds + 2 * BT * LDS_LD;
   const int tid = threadIdx.x, lane = tid & 63;

@@ -27,6 +27,7 @@ static __device__ __forceinline__ double readlane_d(double v, int l) {
 }
 
 #define PLD 129
+#define LEAF_STAMP(k) do { if ((dbg_skip & 8) && tid == 0) info[k] = (int)__builtin_amdgcn_s_memrealtime(); } while (0)
 #define CBLD 132  // published column: 128 values + 1/pivot at [128], padded to a multiple of 2
 
 // Factor of the 16x16 diagonal block at column c0 of the LDS tile, executed by ONE wave, rank-4 updates on the
@@ -38,13 +39,16 @@ static __device__ __forceinline__ double readlane_d(double v, int l) {
 // v_mfma_f64_16x16x4_f64 for the whole trailing block.  ~100 instructions per four columns against ~240 for the
 // lane-per-row version with 15 readlane broadcasts per column (measured 18.5 vs 19.4 us per leaf: the chain of
 // dependent fp64 operations per pivot, not the instruction count, is what is left).
-static __device__ __forceinline__ void leaf_diag_block_mfma(double* S, int c0, int lane, double* rinvb, int* failflag) {
+// Sb: element (0,0) of the block, LD: its row stride in doubles (the full-tile image of the 1024-thread leaf and the
+// block-triangular image of the slot-sized leaf share this code: same operations, same order, same bits).
+template <int LD>
+static __device__ __forceinline__ void leaf_diag_block_mfma(double* Sb, int c0, int lane, double* rinvb, int* failflag) {
   const int r = lane & 15, k = lane >> 4;
   d4 acc;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = k + 4 * q;  // only the lower triangle of the tile is read (LAPACK convention), mirrored
-    acc[q] = (row >= r) ? S[(c0 + row) * PLD + c0 + r] : S[(c0 + r) * PLD + c0 + row];
+    acc[q] = (row >= r) ? Sb[row * LD + r] : Sb[r * LD + row];
   }
   int bad = 0;
 #pragma unroll
@@ -74,7 +78,7 @@ static __device__ __forceinline__ void leaf_diag_block_mfma(double* S, int c0, i
       }
     }
     if (lane < 16) {
-      double* wrow = S + (c0 + r) * PLD + c0 + jb;
+      double* wrow = Sb + r * LD + jb;
 #pragma unroll
       for (int c = 0; c < 4; ++c) wrow[c] = l[c];
     }
@@ -120,7 +124,6 @@ static __device__ __forceinline__ void leaf_body(const double* __restrict__ A, l
   constexpr int algo = ALGO;
   double* colbuf = S + 128 * PLD;       // [2][CBLD]; 128*129 and CBLD are even -> 16-byte aligned pair reads
   double* pivbuf = colbuf + 2 * CBLD;   // [128] pivots
-#define LEAF_STAMP(k) do { if ((dbg_skip & 8) && tid == 0) info[k] = (int)__builtin_amdgcn_s_memrealtime(); } while (0)
   LEAF_STAMP(3);
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int i = e >> 7, j = e & 127;
@@ -241,7 +244,7 @@ static __device__ __forceinline__ void leaf_body(const double* __restrict__ A, l
     __syncthreads();
     int fail = 0;
     const bool run = !(dbg_skip & 1);
-    if (run && wv == 0 && !(dbg_skip & 64)) leaf_diag_block_mfma(S, 0, lane, rinvb, &failflag);
+    if (run && wv == 0 && !(dbg_skip & 64)) leaf_diag_block_mfma<PLD>(S, 0, lane, rinvb, &failflag);
     __syncthreads();
     fail = failflag;
     for (int b = 0; b < 8 && run && !fail; ++b) {
@@ -268,7 +271,7 @@ static __device__ __forceinline__ void leaf_body(const double* __restrict__ A, l
       const int nbk = 7 - b, ntile = nbk * (nbk + 1) / 2;
       if (wv == 0) {
         if (!(dbg_skip & 32)) leaf_update_tile(S, c0, 0, fr, fg);
-        if (!(dbg_skip & 64)) leaf_diag_block_mfma(S, c0 + 16, lane, rinvb, &failflag);
+        if (!(dbg_skip & 64)) leaf_diag_block_mfma<PLD>(S + (c0 + 16) * PLD + c0 + 16, c0 + 16, lane, rinvb, &failflag);
       } else {
         for (int t = wv; t < ntile && !(dbg_skip & 32); t += 15) leaf_update_tile(S, c0, t, fr, fg);
       }
@@ -377,6 +380,216 @@ static __device__ __forceinline__ void leaf_body(const double* __restrict__ A, l
   LEAF_STAMP(7);
 }
 
+
+// ---------------------------------------------------------------- the slot-sized leaf (default)
+// The same blocked algorithm -- operation for operation, so the factor and its inverse are BIT-IDENTICAL to leaf_body<1> --
+// in a workgroup that fits the slot ONE finished trailing-update workgroup frees on a CU: 8 waves of <= 128 VGPRs and 76.6 KiB
+// of LDS (the update kernel holds 64 KiB per workgroup, two per CU, of 160 KiB).  The 1024-thread / 132 KiB form needs an
+// EMPTY CU, which beside thousands of queued update workgroups only a CU mask on the update stream could provide, and a
+// CU-masked queue costs the update kernel ~10 %.  With this form nothing is masked: the leaf is
+// launched on the high-priority chain stream and takes the next slot that frees up anywhere on the chip.
+// LDS image: only the 36 lower 16x16 blocks, block (I, J) at tri_base(I, J) (block-column-major: blocks of one block column
+// are consecutive, so that consecutive block rows sit an odd multiple of 16 doubles apart), rows 17 doubles apart.
+#define TLD 17
+#define TBS (16 * TLD)
+#define TRI_DOUBLES (36 * TBS)
+static __device__ __forceinline__ int tri_base(int I, int J) { return (8 * J - J * (J - 1) / 2 + (I - J)) * TBS; }
+
+// rank-16 update of trailing block t of step b (triangular numbering, block 0 = the next diagonal block)
+static __device__ __forceinline__ void leaf_update_tile_tri(double* S, int b, int t, int fr, int fg) {
+  int I = 0;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int J = t - I * (I + 1) / 2;
+  double* C = S + tri_base(b + 1 + I, b + 1 + J);
+  d4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = C[(fg + 4 * r) * TLD + fr];
+  const double* Ap = S + tri_base(b + 1 + I, b) + fr * TLD + fg;
+  const double* Bp = S + tri_base(b + 1 + J, b) + fr * TLD + fg;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[4 * ks], Bp[4 * ks], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) C[(fg + 4 * r) * TLD + fr] = acc[r];
+}
+
+// S: TRI_DOUBLES doubles of LDS; 512 threads.  dbg_skip: 1 no elimination, 2 no inverse, 8 phase stamps in info[3..7].
+static __device__ __forceinline__ void leaf_body_tri(const double* __restrict__ A, long lda, double* __restrict__ L, long ldl,
+                                                     double* __restrict__ Dinv, int* info, int col0, int dbg_skip, double* S,
+                                                     double* rinvb, int& failflag, const int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  LEAF_STAMP(3);
+  // ---- load the lower blocks: block row I is 16 rows of 16 (I + 1) contiguous doubles
+#pragma unroll
+  for (int I = 0; I < 8; ++I) {
+    const int rl = 16 * (I + 1);
+    for (int e = tid; e < 16 * rl; e += 512) {
+      const int r = e / rl, c = e - r * rl;
+      S[tri_base(I, c >> 4) + r * TLD + (c & 15)] = A[(long)(16 * I + r) * lda + c];
+    }
+  }
+  if (tid == 0) failflag = 0;
+  __syncthreads();
+  LEAF_STAMP(4);
+  // ---- blocked elimination: as leaf_body<1> (8 steps of 16 columns; wave 0 updates and factors the next diagonal block
+  // while waves 1..7 apply the rest of the step's rank-16 update)
+  int fail = 0;
+  const bool run = !(dbg_skip & 1);
+  if (run && wv == 0) leaf_diag_block_mfma<TLD>(S + tri_base(0, 0), 0, lane, rinvb, &failflag);
+  __syncthreads();
+  fail = failflag;
+  for (int b = 0; b < 8 && run && !fail; ++b) {
+    const int nbelow = 112 - 16 * b;
+    if (tid < nbelow) {
+      double* xr = S + tri_base(b + 1 + (tid >> 4), b) + (tid & 15) * TLD;
+      const double* Sd = S + tri_base(b, b);
+      double x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = xr[k];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        x[m] *= rinvb[m];
+#pragma unroll
+        for (int k = m + 1; k < 16; ++k) x[k] = __builtin_fma(-x[m], Sd[k * TLD + m], x[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) xr[k] = x[k];
+    }
+    __syncthreads();
+    if (b == 7) break;
+    const int nbk = 7 - b, ntile = nbk * (nbk + 1) / 2;
+    if (wv == 0) {
+      leaf_update_tile_tri(S, b, 0, fr, fg);
+      leaf_diag_block_mfma<TLD>(S + tri_base(b + 1, b + 1), 16 * b + 16, lane, rinvb, &failflag);
+    } else {
+      for (int t = wv; t < ntile; t += 7) leaf_update_tile_tri(S, b, t, fr, fg);
+    }
+    __syncthreads();
+    fail = failflag;
+  }
+  if (fail) {
+    if (tid == 0) atomicCAS(info, 0, col0 + fail);
+    // keep downstream kernels on finite data: emit identity factors for this tile
+    for (int e = tid; e < 128 * 128; e += 512) {
+      const int ii = e >> 7, jj = e & 127;
+      const double v = (ii == jj) ? 1.0 : 0.0;
+      L[(long)ii * ldl + jj] = v;
+      Dinv[ii * 128 + jj] = v;
+    }
+    return;
+  }
+  for (int e = tid; e < 128 * 128; e += 512) {
+    const int ii = e >> 7, jj = e & 127;
+    L[(long)ii * ldl + jj] = ((jj >> 4) <= (ii >> 4)) ? S[tri_base(ii >> 4, jj >> 4) + (ii & 15) * TLD + (jj & 15)] : 0.0;
+  }
+  __syncthreads();
+  if (tid < 128) {
+    double* dg = S + tri_base(tid >> 4, tid >> 4) + (tid & 15) * (TLD + 1);
+    *dg = 1.0 / *dg;
+  }
+  __syncthreads();
+  LEAF_STAMP(5);
+  if (!(dbg_skip & 2)) {
+    // ---- inverses of the eight diagonal blocks: one wave per block, lane = column (as leaf_body)
+    if (lane < 16) {
+      double* Sd = S + tri_base(wv, wv);
+      const int c = lane;
+      double x[16];
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) {
+        const double* Li = Sd + ii * TLD;
+        const double rii = Li[ii];
+        double sum = 0.0;
+#pragma unroll
+        for (int m = 0; m < ii; ++m) sum = __builtin_fma(Li[m], x[m], sum);
+        x[ii] = (ii == c) ? rii : ((ii > c) ? -sum * rii : 0.0);
+        asm volatile("" : "+v"(x[ii]) : : "memory");
+      }
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii)
+        if (ii >= c) Sd[ii * TLD + c] = x[ii];
+    }
+    __syncthreads();
+    // ---- recursive doubling X21 = -X22 (L21 X11) for block sizes 16, 32, 64: up to 16 output blocks per level, two per
+    // wave.  The zero blocks above the diagonal of X11 / X22 (which the full-tile image multiplies by) are skipped: the
+    // same sums.
+#pragma unroll
+    for (int lv = 0; lv < 3; ++lv) {
+      const int nb = 1 << lv;          // level block size in 16-blocks
+      const int tpp = nb * nb;         // output blocks per pair
+      const int ntile = (4 >> lv) * tpp;  // 4, 8, 16
+      d4 acc[2];
+      int R[2], Cb[2], K0[2], tr[2], tc[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int tile = wv + 8 * u;
+        acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
+        if (tile < ntile) {
+          const int pair = tile / tpp, tt = tile % tpp;
+          K0[u] = 2 * nb * pair;       // first 16-block of X11
+          tr[u] = tt / nb;
+          tc[u] = tt % nb;
+          R[u] = K0[u] + nb + tr[u];
+          Cb[u] = K0[u] + tc[u];
+          // T = L21 X11: A = L21[fr][k + fg] from block (R, K0 + kb), B = X11[k + fg][fr] from block (K0 + kb, Cb), kb >= tc
+          for (int kb = tc[u]; kb < nb; ++kb) {
+            const double* Ap = S + tri_base(R[u], K0[u] + kb) + fr * TLD + fg;
+            const double* Bp = S + tri_base(K0[u] + kb, Cb[u]) + fg * TLD + fr;
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[k], Bp[k * TLD], acc[u], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (wv + 8 * u < ntile) {
+          double* T = S + tri_base(R[u], Cb[u]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T[(fg + 4 * r) * TLD + fr] = acc[u][r];
+        }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
+        if (wv + 8 * u < ntile) {
+          // X21 = -X22 T: A = X22[fr][k + fg] from block (R, K0 + nb + kb), kb <= tr; B = T[k + fg][fr] from block (K0 + nb + kb, Cb)
+          for (int kb = 0; kb <= tr[u]; ++kb) {
+            const double* Ap = S + tri_base(R[u], K0[u] + nb + kb) + fr * TLD + fg;
+            const double* Bp = S + tri_base(K0[u] + nb + kb, Cb[u]) + fg * TLD + fr;
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[k], Bp[k * TLD], acc[u], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (wv + 8 * u < ntile) {
+          double* X = S + tri_base(R[u], Cb[u]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) X[(fg + 4 * r) * TLD + fr] = -acc[u][r];
+        }
+      __syncthreads();
+    }
+  }
+  LEAF_STAMP(6);
+  for (int e = tid; e < 128 * 128; e += 512) {
+    const int ii = e >> 7, jj = e & 127;
+    Dinv[e] = ((jj >> 4) < (ii >> 4) || ((jj >> 4) == (ii >> 4) && jj <= ii)) ? S[tri_base(ii >> 4, jj >> 4) + (ii & 15) * TLD + (jj & 15)] : 0.0;
+  }
+  LEAF_STAMP(7);
+}
+
+__global__ __launch_bounds__(512, 4) void potf2_trtri_128_slot_kernel(const double* __restrict__ A, long lda, double* __restrict__ L,
+                                                                      long ldl, double* __restrict__ Dinv, int* info, int col0,
+                                                                      int dbg_skip) {
+  __shared__ __attribute__((aligned(16))) double S[TRI_DOUBLES];
+  __shared__ double rinvb[16];
+  __shared__ int failflag;
+  leaf_body_tri(A, lda, L, ldl, Dinv, info, col0, dbg_skip, S, rinvb, failflag, (int)threadIdx.x);
+}
+
 template <int ALGO>
 __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __restrict__ A, long lda,
                                                                double* __restrict__ L, long ldl,
@@ -388,10 +601,12 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   leaf_body<ALGO>(A, lda, L, ldl, Dinv, info, col0, dbg_skip, S, rinvb, failflag, (int)threadIdx.x);
 }
 
-int g_leaf_algo = 1;  // 1: blocked elimination (16-column steps, MFMA updates); 0: column-by-column in registers
+int g_leaf_algo = 2;  // 2: slot-sized blocked leaf (512 threads, block-triangular LDS image; default); 1: the same algorithm, 1024 threads on the full tile; 0: column-by-column in registers
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0,
                            int dbg_skip, hipStream_t s) {
-  if (g_leaf_algo == 0)
+  if (g_leaf_algo == 2)
+    hipLaunchKernelGGL(potf2_trtri_128_slot_kernel, dim3(1), dim3(512), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
+  else if (g_leaf_algo == 0)
     hipLaunchKernelGGL(potf2_trtri_128_kernel<0>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
   else
     hipLaunchKernelGGL(potf2_trtri_128_kernel<1>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);

@@ -1,0 +1,75 @@
+/*
+ * gpk_testhooks.h -- measurement and test hooks exported by libgpk.so NEXT TO its API (include/gpk.h).
+ *
+ * Nothing here replaces a reference interface and no integration binds it: bench.py times the hot path through
+ * gpk_bench_posterior / gpk_last_timing, tests/ reach single kernels and the single-process emulation of the
+ * block-cyclic job through gpk_test_*, scripts/ probe the hardware through gpk_bench_* / gpk_debug_*.
+ * Same conventions as gpk.h (host pointers, row-major fp64, 0 = ok).
+ */
+#ifndef GPK_TESTHOOKS_H
+#define GPK_TESTHOOKS_H
+#include "gpk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- measurement hooks (bench.py) ----------------------------------------- */
+/* HIP-event timings (ms) of the stages of the last gpk_fit / gpk_predict on this
+ * process; names: "kbuild","potrf","trailing","panel","solve_y","predict".      */
+int gpk_last_timing(const char* stage, double* ms_out, double* count_out);
+/* algorithmic work (flops for "trailing", bytes for "kbuild") of the launches summed by gpk_last_timing. */
+int gpk_last_timing_work(const char* stage, double* work_out);
+/* Stage inputs once (X,y,Z resident in HBM) and run fit+predict `reps` times
+ * without any host<->device traffic inside the timed region; returns total ms.  */
+int gpk_bench_posterior(const double* X, const double* y, int N, int d, const double* log_hyp,
+                        const double* Z, int M, int warmup, int reps, double* ms_total_out,
+                        double* nlml_out, double* mean_out, double* var_out);
+
+/* ---- kernel-level test hooks (tests/ only; host buffers, row-major) --------- */
+/* C (m x n) = [C -] A (m x k) * B (n x k)^T through the MFMA kernel; tile = 128 or 64. */
+int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile);
+/* the RCCL calls of the multi-rank path (broadcast on the panel stream, all-gather and all-reduce on the update
+ * stream) on a one-rank communicator, payload checked: what a 1-GPU box can verify of gpk_comm.hip. */
+int gpk_test_rccl_selfcheck(int n_doubles);
+/* single-GPU emulation of the P-rank block-cyclic Cholesky: P virtual rank models driven through the production
+ * schedule (potrf_group: per-rank panel / update phases on the panel and update streams, look-ahead), with the
+ * RCCL broadcast replaced by device copies from the owner's model.  P = 1: the production one-GPU factorisation. */
+int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out);
+/* same emulation, every virtual rank builds its own block columns of K(X,X) on the device first. */
+int gpk_test_dist_fit(const double* X, int N, int d, const double* log_hyp, double jitter, int P, double* L_out);
+/* the whole posterior of a P-rank job on P virtual ranks (fit_group + predict_group, all-gather emulated):
+ * nlml_out[P], mean_out / var_out [P][M] = what every rank ends up with. */
+int gpk_test_dist_posterior(const double* X, const double* y, int N, int d, const double* log_hyp, const double* Z,
+                            int M, int P, double* nlml_out, double* mean_out, double* var_out);
+/* probe: shader clock (GHz) sampled on the panel stream while the update stream runs nbig lower updates (m, K = k). */
+int gpk_bench_clock_under_load(int m, int k, int nbig, int nsamp, double* ghz_out, double* tflops_out);
+/* probe: us per step of [leaf + nsmall GEMMs of small_m x 128 x 128] on the panel-chain stream, alone / under load. */
+int gpk_bench_chain_step(int reps, int nsmall, int small_m, double* us_alone, double* us_contended);
+/* device-resident timing of the kernel-matrix builder (mode 0 SE, 1 squared distance, 2 stores only). */
+int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_out);
+/* device-resident timing of the MFMA GEMM: C (m x n) -= A (m x k) B (n x k)^T, `reps` launches; ms per launch. */
+int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out);
+/* LDS banking probe for rocprofv3 --pmc (scripts/lds_bank_probe.sh): `reps` ds_read_b64 per lane in one of six address patterns. */
+int gpk_bench_lds_bank_probe(int pattern, int reps);
+/* the leaf server's bounded wait: a tile posted with no server resident must come back as an error after ~5 s (0 = it did). */
+int gpk_test_leaf_server_timeout(double* seconds_out);
+/* leaf kernel timing; dbg_skip bit0 = skip elimination, bit1 = skip inverse (timing only). */
+int gpk_bench_leaf(int dbg_skip, int reps, double* us_out);
+/* diagnostic: physical placement (xcc<<16 | se<<8 | sh<<4 | cu) of workgroups launched on the GEMM / leaf streams. */
+int gpk_debug_cu_masks(int nmain, unsigned* ids_main, int nleaf, unsigned* ids_leaf);
+/* leaf on the reserved-CU stream, alone and while the GEMM stream saturates the other CUs. */
+int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended);
+/* pure v_mfma_f64_16x16x4_f64 issue loop on every CU: measured fp64 MFMA peak (TFLOP/s) of this device. */
+int gpk_bench_mfma_peak(int iters, double* tflops_out);
+int gpk_bench_mfma_peak2(int nacc, int waves_per_simd, int iters, double* tflops_out);
+/* the same loop with exactly waves_per_simd (1, 2, 4, 8) waves pinned on every SIMD through the LDS allocation;
+   out[6] = TFLOP/s, shader GHz, max / min waves per occupied SIMD, SIMDs occupied, TFLOP/s by the slowest wave's cycles. */
+int gpk_bench_mfma_pinned(int waves_per_simd, int iters, double* out);
+/* factor one 128x128 SPD tile: L_out (128x128 lower) and Dinv_out = inv(L). Returns info. */
+int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPK_TESTHOOKS_H */

@@ -1,5 +1,5 @@
 """CPU: the C-ABI shared library loads and exports every symbol include/gpk.h declares
-(no compute calls: there is no GPU here), and the product path fails loudly without one."""
+(gpk_testhooks.h: the measurement / test hooks exported next to it; no compute calls: there is no GPU here), and the product path fails loudly without one."""
 import os
 import re
 
@@ -10,9 +10,12 @@ from conftest import ROOT
 
 
 def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "gpk.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(gpk_[A-Za-z0-9_]+)\s*\(", txt)))
+    names = set()
+    for h in ("gpk.h", "gpk_testhooks.h"):  # the API, and the measurement / test hooks exported next to it
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(gpk_[A-Za-z0-9_]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():

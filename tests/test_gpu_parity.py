@@ -168,6 +168,35 @@ def test_leaf_factor_and_inverse(gpk):
     assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D)) == 1
 
 
+def test_slot_sized_leaf_is_bitwise_the_full_tile_leaf(gpk):
+    """The default leaf (option leaf_algo = 2: 512 threads, 76.6 KiB block-triangular LDS image -- the slot one finished
+    update workgroup frees, so that no CU has to be reserved for it) performs the operations of the 1024-thread / 132 KiB
+    leaf (leaf_algo = 1) in the same order: factor and inverse agree bit for bit, and so does the failure report."""
+    rng = np.random.RandomState(5)
+    for trial in range(4):
+        Q = rng.randn(128, 128 if trial < 2 else 20)
+        A = Q @ Q.T + (128 if trial % 2 == 0 else 1e-3) * np.eye(128)
+        A[np.triu_indices(128, 1)] = np.nan if trial == 3 else A[np.triu_indices(128, 1)]  # only the lower triangle may be read
+        out = []
+        for algo in (1, 2):
+            gpk.set_option("leaf_algo", algo)
+            L, D = np.zeros((128, 128)), np.zeros((128, 128))
+            assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D)) == 0, gpk.last_error()
+            out.append((L, D))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        assert np.all(np.triu(out[1][0], 1) == 0) and np.all(np.triu(out[1][1], 1) == 0)
+        Lr = np.linalg.cholesky(np.tril(A) + np.tril(A, -1).T)
+        np.testing.assert_allclose(out[1][0], Lr, rtol=1e-9, atol=1e-12)
+    for bad in (0, 15, 16, 77, 127):
+        B = np.eye(128) * 2.0 + 0.01
+        B[bad, bad] = -1.0
+        for algo in (1, 2):
+            gpk.set_option("leaf_algo", algo)
+            L, D = np.zeros((128, 128)), np.zeros((128, 128))
+            assert gpk.lib().gpk_test_potf2_128(_ptr(B), _ptr(L), _ptr(D)) == bad + 1
+            assert np.array_equal(L, np.eye(128)) and np.array_equal(D, np.eye(128))  # identity factors keep downstream kernels finite
+
+
 @pytest.mark.parametrize("N", [1, 2, 5, 127, 128, 129, 300, 640, 1111, 2048])
 def test_potrf_matches_numpy(gpk, N):
     rng = np.random.RandomState(N)
