@@ -18,10 +18,6 @@ int gpk_device_count(void) {
   return n;
 }
 
-// the CU-masked update stream of an earlier gpk_init / gpk_shutdown cycle (see gpk_shutdown)
-static hipStream_t g_parked_main = nullptr;
-static int g_parked_device = -1, g_parked_reserved = 0;
-
 int gpk_init(int device) {
   if (G.inited) {
     if (device == G.device) return 0;
@@ -38,102 +34,27 @@ int gpk_init(int device) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return gpk_set_err(-2, "gpk_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
                        prop.gcnArchName);
-  // Stream layout.  The leaf kernel needs 132 KiB of LDS, i.e. a CU with no trailing-update
-  // workgroup resident; behind a queue of thousands of 64 KiB GEMM workgroups it would starve.
-  // So one CU is reserved (CU mask) for the leaf stream and the GEMM streams get the other 255.
-  const int ncu = prop.multiProcessorCount;
-  const char* env_res = getenv("GPK_RESERVE_CU");  // 0: nothing masked (then option leaf_server defaults to 1)
-  const bool want_reserve = !(env_res && env_res[0] == '0') && ncu >= 64;
-  G.leaf_server = want_reserve ? 0 : 1;
-  bool masked = false;
-  if (want_reserve) {
-    const int words = (ncu + 31) / 32;
-    std::vector<uint32_t> m_all(words, 0u);
-    for (int c = 0; c < ncu; ++c) m_all[c / 32] |= (1u << (c % 32));
-    // One reserved CU PER XCD: a queue whose mask names CUs of a single XCD is still dispatched round-robin over
-    // all 8 XCDs, and on the XCDs where its mask is empty the runtime lets it use every CU (measured with
-    // gpk_debug_cu_masks: a 1-bit mask ran on 57 different CUs), so a lone reserved CU only helps 1 launch in 8.
-    // Mask bit i <-> XCD (i % 8) when GPK_RESERVE_MODE=0 (default), XCD (i / (ncu/8)) when 1.
-    const char* env_mode = getenv("GPK_RESERVE_MODE");
-    const int mode = env_mode ? atoi(env_mode) : 0;
-    const char* env_rn = getenv("GPK_RESERVE_PER_XCD");  // CUs per XCD kept out of the update stream's mask
-    int per_xcd = env_rn ? atoi(env_rn) : 1;
-    if (per_xcd < 1) per_xcd = 1;
-    if (per_xcd > 16) per_xcd = 16;
-    for (int j = 0; j < per_xcd; ++j)
-      for (int x = 0; x < 8; ++x) {
-        const int r = (mode == 0) ? (ncu - 8 * (j + 1) + x) : ((x + 1) * (ncu / 8) - 1 - j);
-        m_all[r / 32] &= ~(1u << (r % 32));
-      }
-    G.ncu_reserved = 8 * per_xcd;
-    hipError_t e1 = hipSuccess;
-    if (g_parked_main && g_parked_device == device && g_parked_reserved == G.ncu_reserved) {
-      G.s_main = g_parked_main;
-      g_parked_main = nullptr;
-    } else {
-      e1 = hipExtStreamCreateWithCUMask(&G.s_main, words, m_all.data());
-    }
-    // s_panel (the latency-critical panel chain): high PRIORITY instead of a mask -- the two cannot be combined
-    // through HIP.  Its skinny GEMMs may also use the reserved CU; a leaf only ever follows them in stream
-    // order, so the CU is empty again when the leaf arrives.  GPK_PANEL_PRIO=0 restores the masked stream.
-    const char* env_pp = getenv("GPK_PANEL_PRIO");
-    const bool panel_prio = !(env_pp && env_pp[0] == '0');
-    int plo = 0, phi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-    hipError_t e2 = e1 != hipSuccess ? e1
-                    : panel_prio     ? hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, phi)
-                                     : hipExtStreamCreateWithCUMask(&G.s_panel, words, m_all.data());
-    // The leaf runs on the panel chain's stream: that stream is unmasked, and the CUs the update stream's mask leaves
-    // out are where its 1024-thread workgroup finds room.  (Round 1 also had a leaf stream of its own, masked to those
-    // CUs: two event hops per leaf cost more than the mask bought.)  The tile pipeline's second chain stream (s_rows)
-    // only exists while option tail_rows > 0: an idle fourth stream costs 4 % at N = 4096 (3.18 -> 3.32 ms, A/B on one box).
-    hipError_t e3 = e2;  // (s_rows is created when the tile pipeline is switched on: option tail_rows)
-    if (e3 == hipSuccess) {
-      // s_pred (forward substitutions pipelined behind the panels): an unmasked stream of its own rather than a
-      // second masked one (round 1: masked, its kernels queued behind thousands of trailing-update workgroups and a
-      // 2.7 ms backlog was left over when the factorisation ended).  High priority.  Round 2 re-measured LOW priority
-      // (below the update stream, whose rest-updates feed the panel chain): N = 16384 28.0-28.1 posteriors/s and
-      // 42.6-43.1 TFLOP/s on the trailing update against 28.0 and 41.5 (A/B/A/B on one box), but N = 4096, where the
-      // substitutions ARE a critical chain, becomes bimodal (3.15 / 3.28-3.33 ms against 3.14-3.15): high stays.
-      // The y substitution shares this stream.  Stream COUNT matters on this part: with the y chain on a stream
-      // of its own the posterior rate at N = 16384 was 23.6 (high priority) / 24.8 (normal) against 25.6 here,
-      // one further idle high-priority stream took it to 19-20, and moving the substitutions onto the panel
-      // chain's stream to 22.4.  Dropping the leaf stream as well (see above) leaves three: update, panel chain,
-      // substitutions.
-      const char* env_qp = getenv("GPK_PRED_PRIO");  // 0: CU mask instead, 2: middle, 3: low, default: HIGH priority
-      if (env_qp && env_qp[0] == '0') e3 = hipExtStreamCreateWithCUMask(&G.s_pred, words, m_all.data());
-      else if (env_qp && env_qp[0] == '2') e3 = hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, (plo + phi) / 2);
-      else if (env_qp && env_qp[0] == '3') e3 = hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, plo);
-      else e3 = hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, phi);
-    }
-    masked = (e3 == hipSuccess);
-    if (!masked) {
-      (void)hipGetLastError();
-      if (G.s_main) (void)hipStreamDestroy(G.s_main);
-      if (G.s_pred && G.s_pred != G.s_panel) (void)hipStreamDestroy(G.s_pred);
-      if (G.s_rows) (void)hipStreamDestroy(G.s_rows);
-      if (G.s_panel) (void)hipStreamDestroy(G.s_panel);
-      G.s_main = G.s_panel = G.s_rows = G.s_pred = nullptr;
-    }
-  }
+  // Stream layout: three streams, no CU mask.  The update stream carries the bulk GEMMs at normal priority; the panel chain
+  // (leaf + skinny GEMMs) and the substitutions pipelined behind the panels run above it.  Rounds 1 and 2 reserved one CU
+  // per XCD for the leaf with a CU mask on the update stream (hipExtStreamCreateWithCUMask); a masked queue places this
+  // kernel's workgroups unevenly and costs it ~10 %, and destroying such a stream made the runtime's
+  // own teardown hang.  The leaf now fits the slot of one finished GEMM workgroup and the GEMM workgroups that share its
+  // CU pause while it runs (gpk_internal.h: guest table), so nothing is reserved and every stream is an ordinary one.
+  // Stream COUNT matters on this part (an idle fourth stream costs 4 % at N = 4096): y and prediction share s_pred.
   int lo = 0, hi = 0;
   GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  if (!masked) {
-    // Nothing masked: the update stream at normal priority, the panel chain and the substitutions above it, and the
-    // leaf on its resident server (LeafSession; the server's stream is created with the first session).
-    const char* env_mp = getenv("GPK_MAIN_PRIO");  // 3: low priority for the update stream
-    GPK_HIP(hipStreamCreateWithPriority(&G.s_main, hipStreamNonBlocking, (env_mp && env_mp[0] == '3') ? lo : (lo + hi) / 2));
-    GPK_HIP(hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, hi));
-    const char* env_qp = getenv("GPK_PRED_PRIO");
-    GPK_HIP(hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking,
-                                        (env_qp && env_qp[0] == '3') ? lo : (env_qp && env_qp[0] == '2') ? (lo + hi) / 2 : hi));
+  GPK_HIP(hipStreamCreateWithPriority(&G.s_main, hipStreamNonBlocking, (lo + hi) / 2));
+  GPK_HIP(hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, hi));
+  GPK_HIP(hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, hi));
+  // guest table of the polite co-residency scheme (gpk_internal.h): one counter per physical CU
+  if (!g_cu_guest) {
+    GPK_HIP(hipMalloc((void**)&g_cu_guest, GPK_GUEST_SLOTS * sizeof(unsigned)));
+    GPK_HIP(hipMemset(g_cu_guest, 0, GPK_GUEST_SLOTS * sizeof(unsigned)));
   }
-  G.cu_reserved = masked;
-  G.ncu = masked ? ncu - G.ncu_reserved : ncu;
   G.device = device;
   {
     // One launch per stream: the runtime builds a stream's hardware queue lazily, so the first real launch on each
-    // stream does not pay for it.  (Not a teardown measure: see gpk_shutdown for what is.)
+    // stream does not pay for it.
     unsigned long long* dtouch = nullptr;
     GPK_HIP(hipMalloc((void**)&dtouch, 64));
     hipStream_t all[3] = {G.s_main, G.s_panel, G.s_pred};
@@ -146,64 +67,30 @@ int gpk_init(int device) {
   return 0;
 }
 
+// Everything this library created is released, in one fixed order, with or without a profiler attached: device drained,
+// pooled memory, events, then the streams.  (The parked-stream rule of round 2 -- a destroyed CU-masked stream made the HIP
+// runtime's exit hang, a live one crashed rocprofv3's finaliser -- went away with the mask.)
 void gpk_shutdown(void) {
   if (!G.inited) return;
-  const bool trace = getenv("GPK_TRACE_SHUTDOWN") != nullptr;
-#define SD_STEP(name, call)                               \
-  do {                                                    \
-    if (trace) fprintf(stderr, "[gpk_shutdown] %s ...", name); \
-    call;                                                 \
-    if (trace) fprintf(stderr, " done\n");                \
-  } while (0)
-  SD_STEP("device sync", (void)hipDeviceSynchronize());
-  SD_STEP("pool free", {
-    for (auto& kv : G.pool)
-      for (void* q : kv.second) (void)hipFree(q);
-  });
+  (void)hipDeviceSynchronize();
+  for (auto& kv : G.pool)
+    for (void* q : kv.second) (void)hipFree(q);
   G.pool.clear();
   G.pool_bytes = 0;
   if (G.dstamps) (void)hipFree(G.dstamps);
   G.dstamps = nullptr;
   G.hstamps.clear();
+  if (g_cu_guest) (void)hipFree(g_cu_guest);
+  g_cu_guest = nullptr;
   timers_reset();
   for (hipEvent_t e : G.ev_free) (void)hipEventDestroy(e);
   G.ev_free.clear();
-  // The CU-masked update stream is NOT destroyed: measured on this pool (scripts/shutdown_probe.py,
-  // profiles/r02_shutdown_probe.txt), hipStreamDestroy of a hipExtStreamCreateWithCUMask stream returns, but the
-  // process then hangs in the HIP runtime's own teardown at exit (3 of 3 after a process that had mostly used that
-  // stream; any destroy order, with or without the warm-up launches of gpk_init), while a process that leaves the
-  // stream to process teardown exits cleanly (4 of 4).  The one exception is a process running under rocprofv3, where
-  // it is the other way round (a live masked stream at exit: SIGSEGV in the tool's __cxa_finalize; destroyed: clean) --
-  // so the stream is destroyed only there (ROCP_TOOL_LIBRARIES set) or on request (GPK_DESTROY_MASKED=1).  A kept
-  // stream is parked and reused by the next gpk_init on the same device.
-  const char* env_dm = getenv("GPK_DESTROY_MASKED");
-  const bool destroy_masked = !G.cu_reserved || (env_dm ? env_dm[0] == '1' : getenv("ROCP_TOOL_LIBRARIES") != nullptr);
-  SD_STEP("destroy s_pred", if (G.s_pred && G.s_pred != G.s_panel) (void)hipStreamDestroy(G.s_pred));
-  G.s_pred = nullptr;
-  if (destroy_masked) {
-    SD_STEP("destroy s_main", if (G.s_main) (void)hipStreamDestroy(G.s_main));
-  } else {
-    g_parked_main = G.s_main;
-    g_parked_device = G.device;
-    g_parked_reserved = G.ncu_reserved;
-  }
-  SD_STEP("destroy s_leaf", if (G.s_leaf) (void)hipStreamDestroy(G.s_leaf));
-  G.s_leaf = nullptr;
-  G.leaf_chain = nullptr;
-  if (G.leaf_mb) (void)hipFree(G.leaf_mb);
-  G.leaf_mb = nullptr;
-  if (G.dflags) (void)hipFree(G.dflags);
-  G.dflags = nullptr;
-  SD_STEP("destroy s_rows", if (G.s_rows) (void)hipStreamDestroy(G.s_rows));
-  SD_STEP("destroy s_comm", if (G.s_comm) (void)hipStreamDestroy(G.s_comm));
-  G.s_comm = nullptr;
-  SD_STEP("destroy s_panel", if (G.s_panel) (void)hipStreamDestroy(G.s_panel));
-  SD_STEP("destroy events", {
-    for (hipEvent_t e : G.ev_dep_free) (void)hipEventDestroy(e);
-  });
-#undef SD_STEP
+  for (hipEvent_t e : G.ev_dep_free) (void)hipEventDestroy(e);
   G.ev_dep_free.clear();
-  G.s_main = G.s_panel = G.s_rows = nullptr;
+  for (hipStream_t* sp : {&G.s_pred, &G.s_comm, &G.s_panel, &G.s_main}) {
+    if (*sp) (void)hipStreamDestroy(*sp);
+    *sp = nullptr;
+  }
   G.inited = false;
 }
 
@@ -215,97 +102,43 @@ int gpk_sync(void) {
   return 0;
 }
 
+// Schedule switches (README.md lists them).  Results do not depend on them beyond rounding, most not at all.
 int gpk_set_option(const char* key, double value) {
   std::string k(key ? key : "");
-  if (k == "nb") {
-    int nb = (int)value;
-    if (nb < 128 || nb % 128) return gpk_set_err(-1, "option nb=%d must be a positive multiple of 128", nb);
-    G.nb = nb;
-    G.nb_auto = 0;  // an explicit panel width switches the automatic schedule off
-  } else if (k == "nb_auto") {
-    G.nb_auto = (int)value;
-  } else if (k == "nb_big") {
-    if ((int)value < 128 || (int)value % 128) return gpk_set_err(-1, "nb_big must be a multiple of 128");
-    G.nb_big = (int)value;
+  const int v = (int)value;
+  if (k == "nb") {  // 0: the automatic 512 / 256 / 128 schedule (default); otherwise uniform panels of this width
+    if (v < 0 || v % 128) return gpk_set_err(-1, "option nb=%d must be 0 (automatic) or a positive multiple of 128", v);
+    G.nb = v;
   } else if (k == "nb_big_until") {
-    G.nb_big_until = (int)value;
-  } else if (k == "nb_small") {
-    if ((int)value < 128 || (int)value % 128) return gpk_set_err(-1, "nb_small must be a multiple of 128");
-    G.nb_small = (int)value;
+    G.nb_big_until = v;
   } else if (k == "nb_small_from") {
-    G.nb_small_from = (int)value;
-  } else if (k == "outer_until") {
-    G.outer_until = (int)value;
-  } else if (k == "outer_from") {
-    G.outer_from = (int)value;
+    G.nb_small_from = v;
   } else if (k == "nb_outer") {
-    G.nb_outer = (int)value;
+    G.nb_outer = v;
+  } else if (k == "outer_until") {
+    G.outer_until = v;
   } else if (k == "lookahead") {
-    G.lookahead = (int)value;
-  } else if (k == "pred_gate_rows") {
-    G.pred_gate_rows = (int)value;
-  } else if (k == "ldk_pad") {
-    if ((int)value < 0 || (int)value > 4096 || ((int)value & 1)) return gpk_set_err(-1, "ldk_pad must be an even number in 0..4096");
-    G.ldk_pad = (int)value;
+    G.lookahead = v;
   } else if (k == "dist_group") {
-    if ((int)value < 1 || (int)value > 64) return gpk_set_err(-1, "dist_group must be in 1..64");
-    G.dist_group = (int)value;
-  } else if (k == "gemm_variant") {
-    extern int g_gemm_variant;
-    g_gemm_variant = (int)value;
-  } else if (k == "xcd_sq") {
-    G.xcd_sq = (int)value;
-  } else if (k == "xcd_sq_min_tiles") {
-    G.xcd_sq_min_tiles = (int)value;
-  } else if (k == "xcd_sorted") {
-    G.xcd_sorted = (int)value ? 1 : 0;
-  } else if (k == "tail_flags") {
-    G.tail_flags = (int)value ? 1 : 0;
-  } else if (k == "tail_leaf_event") {
-    G.tail_leaf_event = (int)value ? 1 : 0;
-  } else if (k == "tt_fused") {
-    G.tt_fused = (int)value ? 1 : 0;
-  } else if (k == "tail_stream" || k == "tail_rows") {
-    // the tile pipeline's own stream (s_rows) exists exactly while tail_rows > 0 AND tail_stream == 1: an idle fourth
-    // stream costs 4 % at N = 4096
-    if (k == "tail_stream") G.tail_stream = (int)value ? 1 : 0;
-    else G.tail_rows = (int)value;
-    const bool want = G.tail_rows > 0 && G.tail_stream;
-    if (G.inited && want && !G.s_rows) {
-      int lo_ = 0, hi_ = 0;
-      GPK_HIP(hipDeviceGetStreamPriorityRange(&lo_, &hi_));
-      GPK_HIP(hipStreamCreateWithPriority(&G.s_rows, hipStreamNonBlocking, hi_));
-    } else if (G.inited && !want && G.s_rows) {
-      GPK_HIP(hipDeviceSynchronize());
-      GPK_HIP(hipStreamDestroy(G.s_rows));
-      G.s_rows = nullptr;
-    }
-  } else if (k == "stamps") {
-    G.stamps = (int)value;
-  } else if (k == "pred_small_below") {
-    G.pred_small_below = (int)value;
-  } else if (k == "small_tile_below") {
-    G.small_tile_below = (int)value;
-  } else if (k == "leaf_algo") {
-    extern int g_leaf_algo;
-    g_leaf_algo = (int)value;
-  } else if (k == "test_gemm_k1") {
-    G.test_gemm_k1 = (int)value;
+    if (v < 1 || v > 64) return gpk_set_err(-1, "dist_group must be in 1..64");
+    G.dist_group = v;
+  } else if (k == "tail_rows") {
+    G.tail_rows = v;
+  } else if (k == "leaf_fat_rows") {  // the full-tile leaf once at most this many rows remain; -1: never, 1 << 30: always
+    G.leaf_fat_rows = v;
+  } else if (k == "gemm_polite") {
+    extern int g_gemm_polite;
+    g_gemm_polite = v ? 1 : 0;
   } else if (k == "pair_update") {
-    G.pair_update = (int)value;
-  } else if (k == "gemm_pipe") {
-    extern int g_gemm_pipe;
-    g_gemm_pipe = (int)value;
-  } else if (k == "leaf_server") {
-    G.leaf_server = (int)value ? 1 : 0;
-  } else if (k == "pipe_interleave") {
-    G.pipe_interleave = (int)value;
+    G.pair_update = v;
   } else if (k == "fuse_predict") {
-    G.fuse_predict = (int)value;
-  } else if (k == "solve_gemm_above") {
-    G.solve_gemm_above = (int)value;
+    G.fuse_predict = v;
+  } else if (k == "small_tile_below") {
+    G.small_tile_below = v;
+  } else if (k == "stamps") {
+    G.stamps = v;
   } else if (k == "timing") {
-    G.timing = (int)value;
+    G.timing = v;
     if (!G.timing) timers_reset();
   } else {
     return gpk_set_err(-1, "unknown option '%s'", k.c_str());
@@ -315,51 +148,31 @@ int gpk_set_option(const char* key, double value) {
 double gpk_get_option(const char* key) {
   std::string k(key ? key : "");
   if (k == "nb") return G.nb;
+  if (k == "nb_big_until") return G.nb_big_until;
+  if (k == "nb_small_from") return G.nb_small_from;
+  if (k == "nb_outer") return G.nb_outer;
+  if (k == "outer_until") return G.outer_until;
   if (k == "lookahead") return G.lookahead;
   if (k == "dist_group") return G.dist_group;
-  if (k == "ldk_pad") return G.ldk_pad;
-  if (k == "pred_gate_rows") return G.pred_gate_rows;
+  if (k == "tail_rows") return G.tail_rows;
+  if (k == "leaf_fat_rows") return G.leaf_fat_rows;
+  if (k == "gemm_polite") { extern int g_gemm_polite; return g_gemm_polite; }
+  if (k == "pair_update") return G.pair_update;
+  if (k == "fuse_predict") return G.fuse_predict;
+  if (k == "small_tile_below") return G.small_tile_below;
+  if (k == "stamps") return G.stamps;
   if (k == "timing") return G.timing;
+  // read-only state
   if (k == "pool_bytes") return (double)G.pool_bytes;
   if (k == "potrf_enqueue_ms") return G.last_potrf_enqueue_ms;
   if (k == "pipe_enqueue_ms") return G.last_pipe_enqueue_ms;
-  if (k == "cu_reserved") return G.cu_reserved ? 1.0 : 0.0;
   if (k == "potrf_lookahead_used") return g_potrf_lookahead_used;
   if (k == "dist_lookahead_used") return g_dist_lookahead_used;
-  if (k == "nb_auto") return G.nb_auto;
-  if (k == "nb_big") return G.nb_big;
-  if (k == "nb_big_until") return G.nb_big_until;
-  if (k == "nb_small") return G.nb_small;
-  if (k == "nb_small_from") return G.nb_small_from;
-  if (k == "outer_until") return G.outer_until;
-  if (k == "outer_from") return G.outer_from;
-  if (k == "nb_outer") return G.nb_outer;
-  if (k == "xcd_sq") return G.xcd_sq;
-  if (k == "xcd_sq_min_tiles") return G.xcd_sq_min_tiles;
-  if (k == "pred_small_below") return G.pred_small_below;
-  if (k == "small_tile_below") return G.small_tile_below;
-  if (k == "pair_update") return G.pair_update;
-  if (k == "leaf_server") return G.leaf_server;
-  if (k == "gemm_pipe") { extern int g_gemm_pipe; return g_gemm_pipe; }
-  if (k == "cu_reserved") return G.cu_reserved ? G.ncu_reserved : 0;
-  if (k == "pipe_interleave") return G.pipe_interleave;
-  if (k == "fuse_predict") return G.fuse_predict;
-  if (k == "solve_gemm_above") return G.solve_gemm_above;
-  if (k == "stamps") return G.stamps;
-  if (k == "tail_rows") return G.tail_rows;
-  if (k == "tail_stream") return G.tail_stream;
-  if (k == "tt_fused") return G.tt_fused;
-  if (k == "tail_leaf_event") return G.tail_leaf_event;
-  if (k == "tail_flags") return G.tail_flags;
-  if (k == "xcd_sorted") return G.xcd_sorted;
   if (k == "potrf_tail_from") { extern int g_potrf_tail_from; return g_potrf_tail_from; }
-  if (k == "test_gemm_k1") return G.test_gemm_k1;
-  if (k == "leaf_algo") { extern int g_leaf_algo; return g_leaf_algo; }
-  if (k == "gemm_variant") { extern int g_gemm_variant; return g_gemm_variant; }
   // diagnostic stamps of the last fused fit: "stamp_panel_<p>" / "stamp_subst_<p>" in ms after panel 0
   if (k.rfind("stamp_", 0) == 0 && G.hstamps.size() == 1024 && G.hstamps[0]) {
     const bool subst = k.rfind("stamp_subst_", 0) == 0;
-    const int p = atoi(k.c_str() + (subst ? 12 : 12));
+    const int p = atoi(k.c_str() + 12);
     if (p < 0 || p >= 512) return NAN;
     const unsigned long long v = G.hstamps[(subst ? 512 : 0) + p];
     return v ? (double)((long long)(v - G.hstamps[0])) * 1e-5 : NAN;
@@ -455,7 +268,6 @@ int gpk_potrf(double* A, int N) {
     int hinfo = 0;
     if (hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
     if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "potrf: %s", hipGetErrorString(hipGetLastError())); break; }
-    if (hinfo >= LEAF_SERVER_INFO_POISON) { rc = gpk_set_err(-3, "gpk_potrf: the resident leaf server did not answer (mailbox time-out)"); break; }
     if (hinfo > 0) { rc = hinfo > N ? N : hinfo; gpk_set_err(rc, "matrix is not positive definite (leading minor %d)", rc); break; }
     rc = model_unpack_L(m, A);
   } while (0);
@@ -869,7 +681,8 @@ int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
   return model_unpack_L(job.ms[P - 1], L_out);
 }
 
-int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile) {
+int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile, int k1,
+                     int xcd_order) {
   GPK_TRY(rt_require());
   if (!A || !B || !C || m < 1 || n < 1 || k < 1) return gpk_set_err(-1, "gpk_test_gemm_nt: bad arguments");
   hipStream_t s = G.s_main;
@@ -884,8 +697,7 @@ int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, 
   GemmNT g{};
   g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
   g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
-  g.xcd_sq = (G.xcd_sq == 2 && tile == 128) ? (1 | (G.xcd_sorted ? 4 : 0)) : 0;  // option xcd_sq = 2: force the XCD-aware tile order (tests)
-  const int k1 = G.test_gemm_k1;
+  g.xcd_sq = (xcd_order && tile == 128) ? 1 : 0;  // force the XCD-aware 8x8-square tile order of the largest updates
   if (k1 > 0 && k1 < k) {
     // same product with the K range split over two separately stored operands (the paired trailing update);
     // second segment stored separately but with the same leading dimension k (columns [0, k2) used)
@@ -902,7 +714,7 @@ int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, 
   return 0;
 }
 
-int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out) {
+int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out, int full_tile) {
   GPK_TRY(rt_require());
   hipStream_t s = G.s_main;
   double *dA = nullptr, *dL = nullptr, *dD = nullptr;
@@ -915,7 +727,7 @@ int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out) {
   do {
     if (hipMemcpyAsync(dA, A, 128 * 128 * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
     if (hipMemsetAsync(dinfo, 0, 16, s) != hipSuccess) { rc = gpk_set_err(-2, "memset failed"); break; }
-    rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, 0, s);
+    rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, 0, s, full_tile ? 1 : 0);
     if (rc) break;
     if (hipMemcpyAsync(L_out, dL, 128 * 128 * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
     if (hipMemcpyAsync(Dinv_out, dD, 128 * 128 * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
@@ -988,79 +800,9 @@ extern "C" int gpk_test_dist_posterior(const double* X, const double* y, int N, 
 #ifndef GPK_HOSTSIM  // device-only probes (MFMA builtins, hardware registers): not part of the host-side sanitizer build
 // ---------------------------------------------------------------- micro-benchmarks
 typedef double d4_t __attribute__((ext_vector_type(4)));
-template <int NACC>
-__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters, double seed) {
-  d4_t acc[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) acc[i] = (d4_t){0, 0, 0, 0};
-  double a = seed + threadIdx.x * 1e-3 * seed, b = seed - threadIdx.x * 1e-3 * seed;
-  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < NACC; ++i)  // inline asm with "+v": accumulators stay in VGPRs, no AGPR copies
-      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
-  }
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  if (blockIdx.x == 7 && threadIdx.x == 0) {  // shader clock = d(memtime)/d(memrealtime) x 100 MHz
-    reinterpret_cast<unsigned long long*>(out)[(size_t)gridDim.x * blockDim.x] = c1 - c0;
-    reinterpret_cast<unsigned long long*>(out)[(size_t)gridDim.x * blockDim.x + 1] = r1 - r0;
-  }
-  double s = 0;
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-extern "C" {
-
-// nacc in {1,2,4,8,16,32} independent accumulators per wave; waves_per_simd in {1,2,3,4}
-int gpk_bench_mfma_peak2(int nacc, int waves_per_simd, int iters, double* tflops_out) {
-  GPK_TRY(rt_require());
-  const double seed = (iters < 0) ? 0.0 : 0.5;  // negative iters: all-zero operands (lowest switching power)
-  if (iters < 0) iters = -iters;
-  hipStream_t s = G.s_main;
-  const int blocks = 256 * waves_per_simd;
-  double* d = nullptr;
-  GPK_TRY(dev_alloc_t(&d, (size_t)blocks * 256 + 2));
-  hipEvent_t e0, e1;
-  GPK_HIP(hipEventCreate(&e0));
-  GPK_HIP(hipEventCreate(&e1));
-  auto go = [&](int n) {
-    switch (nacc) {
-      case 1: hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
-      case 2: hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
-      case 4: hipLaunchKernelGGL(mfma_peak_kernel<4>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
-      case 8: hipLaunchKernelGGL(mfma_peak_kernel<8>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
-      case 16: hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
-      default: hipLaunchKernelGGL(mfma_peak_kernel<32>, dim3(blocks), dim3(256), 0, s, d, n, seed); break;
-    }
-  };
-  go(iters / 10 + 1);
-  GPK_HIP(hipEventRecord(e0, s));
-  go(iters);
-  GPK_HIP(hipEventRecord(e1, s));
-  GPK_HIP(hipEventSynchronize(e1));
-  float ms = 0;
-  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
-  const double flops = (double)blocks * 4 * (double)iters * (nacc > 16 ? 32 : nacc) * 2048.0;
-  if (tflops_out) *tflops_out = flops / (ms * 1e-3) / 1e12;
-  unsigned long long clk[2] = {0, 0};
-  GPK_HIP(hipMemcpy(clk, d + (size_t)blocks * 256, 16, hipMemcpyDeviceToHost));
-  if (tflops_out && clk[1]) tflops_out[1] = (double)clk[0] / (double)clk[1] * 0.1;  // GHz
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  dev_free(d, (size_t)blocks * 256 * 8);
-  return 0;
-}
-
-int gpk_bench_mfma_peak(int iters, double* tflops_out) { return gpk_bench_mfma_peak2(8, 2, iters, tflops_out); }
-
-}  // extern "C"
-
-// The same issue loop with the residency PINNED: a workgroup of 4 waves (one per SIMD) owns 160 KiB / W of LDS, so a CU
-// holds exactly W of them and a grid of 256 * W workgroups puts W waves on every SIMD.  (gpk_bench_mfma_peak2 leaves the
-// placement to the dispatcher, which stacks W + 1 workgroups on some CUs: its n/(n+1) "ceiling" is load imbalance.)
+// fp64 MFMA issue loop with the residency PINNED: a workgroup of 4 waves (one per SIMD) owns 160 KiB / W of LDS, so a CU
+// holds exactly W of them and a grid of 256 * W workgroups puts W waves on every SIMD.  (Left to the dispatcher, an
+// exact-fit grid stacks W + 1 workgroups on some CUs: the n/(n+1) "ceilings" of rounds 1-2 were load imbalance.)
 template <int W, int NACC, int THREADS = 256>
 __global__ __launch_bounds__(THREADS) void mfma_pinned_kernel(double* out, unsigned* where, int iters, double seed) {
   __shared__ double pin[(160 * 1024 / W) * (THREADS / 256) / 8];
@@ -1100,7 +842,7 @@ int gpk_bench_mfma_pinned(int waves_per_simd, int iters, double* out) {
   if (iters <= 0) return gpk_set_err(-1, "gpk_bench_mfma_pinned: iters must be positive");
   const int W = waves_per_simd;
   if (W != 1 && W != 2 && W != 4 && W != 8) return gpk_set_err(-1, "gpk_bench_mfma_pinned: waves_per_simd must be 1, 2, 4 or 8");
-  hipStream_t s = (G.s_pred && !getenv("GPK_BENCH_MASKED")) ? G.s_pred : G.s_main;  // s_pred is unmasked: all 256 CUs
+  hipStream_t s = G.s_main;
   const int threads = getenv("GPK_BENCH_THREADS") ? atoi(getenv("GPK_BENCH_THREADS")) : 256;
   if (threads != 256 && !(W == 4 && (threads == 512 || threads == 1024)))
     return gpk_set_err(-1, "gpk_bench_mfma_pinned: 512 / 1024 threads only with 4 waves per SIMD");
@@ -1214,48 +956,6 @@ int gpk_bench_lds_bank_probe(int pattern, int reps) {
   return 0;
 }
 
-// A tile posted to the leaf server's mailbox while NO server is resident: the proxy must give up after its bounded wait
-// (LEAF_SERVER_LIMIT_TICKS = 5 s), raise the mailbox's error flag and poison *info.  Returns 0 when exactly that happened;
-// *seconds_out = how long the proxy waited.  (What a lost server -- or a server stream that shares a hardware queue with
-// the chain, GPU_MAX_HW_QUEUES too small -- looks like to the caller: an error, not a hang.)
-int gpk_test_leaf_server_timeout(double* seconds_out) {
-  GPK_TRY(rt_require());
-  if (G.leaf_chain) return gpk_set_err(-1, "gpk_test_leaf_server_timeout: a leaf session is open");
-  GPK_HIP(hipDeviceSynchronize());
-  if (!G.leaf_mb) {
-    GPK_HIP(hipMalloc((void**)&G.leaf_mb, sizeof(LeafMailbox)));
-    GPK_HIP(hipMemset(G.leaf_mb, 0, sizeof(LeafMailbox)));
-    G.leaf_seq = 1;
-  }
-  GPK_HIP(hipMemset(&G.leaf_mb->err, 0, 4));
-  Scratch sc;
-  int* dinfo = nullptr;
-  GPK_TRY(sc.get(&dinfo, 4));
-  GPK_HIP(hipMemset(dinfo, 0, 16));
-  hipEvent_t e0, e1;
-  GPK_HIP(hipEventCreate(&e0));
-  GPK_HIP(hipEventCreate(&e1));
-  GPK_HIP(hipEventRecord(e0, G.s_panel));
-  int rc = launch_leaf_proxy(G.leaf_mb, G.leaf_seq++, 0, nullptr, 0, nullptr, 0, nullptr, dinfo, 0, G.s_panel);
-  GPK_HIP(hipEventRecord(e1, G.s_panel));
-  GPK_HIP(hipEventSynchronize(e1));
-  float ms = 0;
-  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  if (seconds_out) *seconds_out = ms * 1e-3;
-  int hinfo = 0;
-  unsigned herr = 0;
-  GPK_HIP(hipMemcpy(&hinfo, dinfo, 4, hipMemcpyDeviceToHost));
-  GPK_HIP(hipMemcpy(&herr, &G.leaf_mb->err, 4, hipMemcpyDeviceToHost));
-  GPK_HIP(hipMemset(&G.leaf_mb->err, 0, 4));
-  if (rc) return rc;
-  if (hinfo != LEAF_SERVER_INFO_POISON || herr != 2u)
-    return gpk_set_err(-1, "leaf proxy without a server: info = %d (expected %d), mailbox error flag = %u (expected 2)", hinfo,
-                       LEAF_SERVER_INFO_POISON, herr);
-  return 0;
-}
-
 int gpk_bench_leaf(int dbg_skip, int reps, double* us_out) {
   GPK_TRY(rt_require());
   hipStream_t s = G.s_main;
@@ -1270,12 +970,14 @@ int gpk_bench_leaf(int dbg_skip, int reps, double* us_out) {
     for (int j = 0; j < 128; ++j) h[i * 128 + j] = (i == j ? 4.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
   GPK_HIP(hipMemcpyAsync(dA, h.data(), 128 * 128 * 8, hipMemcpyHostToDevice, s));
   GPK_HIP(hipMemsetAsync(dinfo, 0, 16, s));
-  int rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg_skip, s);
+  const int fat = (dbg_skip >> 8) & 1;  // bit 8: the full-tile form
+  dbg_skip &= 0xff;
+  int rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg_skip, s, fat);
   hipEvent_t e0, e1;
   GPK_HIP(hipEventCreate(&e0));
   GPK_HIP(hipEventCreate(&e1));
   GPK_HIP(hipEventRecord(e0, s));
-  for (int r = 0; r < reps && !rc; ++r) rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg_skip, s);
+  for (int r = 0; r < reps && !rc; ++r) rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg_skip, s, fat);
   GPK_HIP(hipEventRecord(e1, s));
   GPK_HIP(hipEventSynchronize(e1));
   float ms = 0;
@@ -1290,44 +992,10 @@ int gpk_bench_leaf(int dbg_skip, int reps, double* us_out) {
   return rc;
 }
 
-// which physical CU does a workgroup run on?  (XCC id, SE id, CU id from the hardware id registers)
-__global__ void whoami_kernel(unsigned* out, int spin) {
-  unsigned hw = 0, xcc = 0;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);
-  if (threadIdx.x == 0) {
-    out[2 * blockIdx.x] = hw;
-    out[2 * blockIdx.x + 1] = xcc;
-  }
-}
-
-// returns in ids_main[0..nmain) / ids_leaf[0..nleaf) a packed (xcc<<16 | se<<8 | cu) per workgroup
-int gpk_debug_cu_masks(int nmain, unsigned* ids_main, int nleaf, unsigned* ids_leaf) {
-  GPK_TRY(rt_require());
-  unsigned *d1 = nullptr, *d2 = nullptr;
-  GPK_TRY(dev_alloc_t(&d1, (size_t)2 * nmain));
-  GPK_TRY(dev_alloc_t(&d2, (size_t)2 * nleaf));
-  hipLaunchKernelGGL(whoami_kernel, dim3(nmain), dim3(256), 0, G.s_main, d1, 200);
-  hipLaunchKernelGGL(whoami_kernel, dim3(nleaf), dim3(1024), 0, G.s_panel ? G.s_panel : G.s_main, d2, 50);
-  GPK_HIP(hipDeviceSynchronize());
-  std::vector<unsigned> h1(2 * nmain), h2(2 * nleaf);
-  GPK_HIP(hipMemcpy(h1.data(), d1, h1.size() * 4, hipMemcpyDeviceToHost));
-  GPK_HIP(hipMemcpy(h2.data(), d2, h2.size() * 4, hipMemcpyDeviceToHost));
-  auto pack = [](unsigned hw, unsigned xcc) {
-    const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 0x1, se = (hw >> 13) & 0x7;  // gfx9 HW_ID layout
-    return ((xcc & 0xf) << 16) | (se << 8) | (sh << 4) | cu;
-  };
-  for (int i = 0; i < nmain; ++i) ids_main[i] = pack(h1[2 * i], h1[2 * i + 1]);
-  for (int i = 0; i < nleaf; ++i) ids_leaf[i] = pack(h2[2 * i], h2[2 * i + 1]);
-  dev_free(d1, (size_t)2 * nmain * 4);
-  dev_free(d2, (size_t)2 * nleaf * 4);
-  return 0;
-}
-
-// leaf kernel on the reserved-CU stream while the GEMM stream keeps the rest of the chip busy
+// leaf kernel on the chain stream while the update stream keeps the chip busy (reps bit 24: the full-tile form)
 int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended) {
-  const int dbg = reps >> 16;  // upper bits: leaf dbg_skip mode
+  const int fat = (reps >> 24) & 1;
+  const int dbg = (reps >> 16) & 0xff;  // leaf dbg_skip mode
   reps &= 0xffff;
   GPK_TRY(rt_require());
   hipStream_t sl = G.s_panel ? G.s_panel : G.s_main, sm = G.s_main;
@@ -1353,7 +1021,7 @@ int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended) {
   GPK_HIP(hipEventCreate(&e1));
   auto run_leaves = [&](double* out) -> int {
     GPK_HIP(hipEventRecord(e0, sl));
-    for (int r = 0; r < reps; ++r) GPK_TRY(launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg, sl));
+    for (int r = 0; r < reps; ++r) GPK_TRY(launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg, sl, fat));
     GPK_HIP(hipEventRecord(e1, sl));
     GPK_HIP(hipEventSynchronize(e1));
     float ms = 0;
@@ -1475,7 +1143,6 @@ int gpk_bench_chain_step(int reps, int nsmall, int small_m, double* us_alone, do
     return 0;
   };
   {
-    LeafSession leaf_session(sl);  // (no device-wide synchronisation while it is open: the server only leaves on its quit message)
     GPK_TRY(run_chain(us_alone));
     GemmNT g{};
     g.A = gA; g.lda = gk; g.B = gA; g.ldb = gk; g.C = gC; g.ldc = gm; g.m = gm; g.n = gm; g.k = gk; g.sub = 1; g.lower = 1;
@@ -1526,7 +1193,7 @@ int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_o
 
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out) {
   GPK_TRY(rt_require());
-  hipStream_t s = (getenv("GPK_BENCH_UNMASKED") && G.s_pred) ? G.s_pred : G.s_main;
+  hipStream_t s = G.s_main;
   double *dA = nullptr, *dB = nullptr, *dC = nullptr;
   GPK_TRY(dev_alloc_t(&dA, (size_t)m * k));
   GPK_TRY(dev_alloc_t(&dC, (size_t)m * n));
@@ -1541,12 +1208,30 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
   GemmNT g{};
   g.A = dA; g.lda = k; g.B = lower ? dA : dB; g.ldb = k; g.C = dC; g.ldc = n;
   g.m = m; g.n = n; g.k = k; g.sub = 1; g.lower = lower & 1;
-  g.xcd_sq = G.xcd_sq ? (G.xcd_sq | (G.xcd_sorted ? 4 : 0)) : 0;
-  extern int g_gemm_variant;
-  const int saved_variant = g_gemm_variant;
-  if (tile == 4) g_gemm_variant = 4;
-  if (tile == 8) g_gemm_variant = 8;
-  auto go = [&]() { return launch_gemm_nt(g, tile != 64, s); };
+  auto go = [&]() { return tile == 64 ? launch_gemm_nt(g, false, s) : launch_gemm_auto(g, s); };
+#ifdef GPK_GEMM_DBG_VARIANTS
+  // GPK_GEMM_TRACE=<file> with GPK_GEMM_DBG=32: per-workgroup stamps of ONE launch (after a warm-up launch) as raw u64[5] records
+  extern unsigned long long* g_gemm_trace;
+  if (getenv("GPK_GEMM_TRACE") && tile != 64) {
+    const size_t nw = (size_t)5 * 65536;
+    unsigned long long* dtr = nullptr;
+    GPK_HIP(hipMalloc((void**)&dtr, nw * 8));
+    GPK_HIP(hipMemset(dtr, 0, nw * 8));
+    (void)go();
+    GPK_HIP(hipStreamSynchronize(s));
+    g_gemm_trace = dtr;
+    (void)go();
+    GPK_HIP(hipStreamSynchronize(s));
+    g_gemm_trace = nullptr;
+    std::vector<unsigned long long> h(nw);
+    GPK_HIP(hipMemcpy(h.data(), dtr, nw * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dtr);
+    if (FILE* f = fopen(getenv("GPK_GEMM_TRACE"), "wb")) {
+      fwrite(h.data(), 8, nw, f);
+      fclose(f);
+    }
+  }
+#endif
   int rc = go();
   hipEvent_t e0, e1;
   GPK_HIP(hipEventCreate(&e0));
@@ -1558,7 +1243,6 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
   float ms = 0;
   GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
   if (ms_out) *ms_out = ms / reps;
-  g_gemm_variant = saved_variant;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   dev_free(dA, (size_t)m * k * 8);

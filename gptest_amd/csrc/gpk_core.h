@@ -19,66 +19,51 @@ struct StageTimer {
 struct Runtime {
   bool inited = false;
   int device = 0;
+  // Three streams, none of them CU-masked.  The update stream (normal priority) carries the bulk GEMMs; the panel chain
+  // and the substitutions run above it.  The latency-critical leaf no longer needs reserved CUs: it takes the slot one
+  // finished GEMM workgroup frees and the GEMM workgroups that share its CU pause while it runs (gpk_internal.h).
   hipStream_t s_main = nullptr, s_panel = nullptr;
   hipStream_t s_pred = nullptr;   // y and prediction substitutions pipelined behind the factorisation (fused fit+predict)
   hipStream_t s_comm = nullptr;   // multi-rank processes: the panel broadcasts (off the panel chain); virtual ranks use s_pred
-  hipStream_t s_rows = nullptr;   // tile pipeline of the chain-bound tail: the full-height panel GEMMs (s_panel keeps the leaves)
-  bool cu_reserved = false;
-  int ncu_reserved = 8;
-  // resident leaf server (gpk_internal.h: LeafMailbox): its stream, its mailbox, the next sequence number, and the
-  // chain stream of the open session (nullptr: none open, leaves are launched directly)
-  hipStream_t s_leaf = nullptr;
-  LeafMailbox* leaf_mb = nullptr;
-  unsigned leaf_seq = 1;
-  hipStream_t leaf_chain = nullptr;
-  int leaf_server = 1;  // option: 0 = always launch the leaf kernel directly
   std::map<size_t, std::vector<void*>> pool;
   size_t pool_bytes = 0;
-  // options
-  int nb = 256;
-  // single-GPU panel schedule: wide panels (K = nb_big) while the trailing matrix is large and the panel
-  // chain hides behind the update, nb in the middle, nb_small at the tail where the chain IS the critical path
-  int nb_big = 512, nb_big_until = 8192, nb_small = 128, nb_small_from = 4096, nb_auto = 1;
-  // two-level blocking (single GPU, nb_auto): OUTER panels of nb_outer columns are applied to the trailing matrix as
-  // ONE update with K = nb_outer (the kernel does 56 TFLOP/s at K = 2048 against 44 at K = 256: the C tile traffic
-  // and the accumulator hand-over amortise over 8x the flops); inside an outer block column the panels above are the
-  // inner level.  Active for Npad >= outer_from while more than outer_until columns remain; 0 = one level.
-  int nb_outer = 2048, outer_from = 24576, outer_until = 8192;  // N = 16384: no gain; N = 32768: 230.6 -> 225.2 ms
+  // ---- options (gpk_set_option).  Panel schedule: nb = 0 is the automatic one -- 512-wide panels while more than
+  // nb_big_until + 512 columns remain (K = 512: the update kernel runs faster and the longer panel chain still hides), 256 in
+  // the middle, 128 for the last nb_small_from columns, where the chain IS the critical path; nb > 0: uniform panels.
+  int nb = 0;
+  int nb_big_until = 8192, nb_small_from = 4096;
+  // two-level blocking (single GPU, automatic schedule): OUTER panels of nb_outer columns are applied to the trailing matrix
+  // as ONE update with K = nb_outer; inside an outer block column the panels above are the inner level.  Active for
+  // Npad >= 3 * outer_until while more than outer_until columns remain; nb_outer = 0: one level.
+  // (N = 16384: no gain; N = 32768: 230.6 -> 225.2 ms.)
+  int nb_outer = 2048, outer_until = 8192;
   int lookahead = 1;
-  int pred_gate_rows = 0;  // experiment: substitutions start when this few columns remain (0: at once)
-  int ldk_pad = 0;      // extra doubles per row of K (single GPU)
-  int dist_group = 2;   // panels per ownership block of a block-cyclic (multi-GPU) model
+  int dist_group = 2;   // panels (of the middle width) per ownership block of a block-cyclic (multi-GPU) model
   // tile pipeline (potrf_tail) for the chain-bound last tail_rows columns (needs 128-wide panels there: nb_small_from);
   // 0 = the panel-level look-ahead everywhere
   int tail_rows = 4096;
-  int tail_flags = 0;       // tile pipeline: flag-chained steps (leaf kernels on the chain stream, T kernels on the update stream, flags in HBM)
-  unsigned* dflags = nullptr;  // 4 words per tile step (leaf flag, tt flag, two counters), zeroed at the start of a factorisation
-  int tail_leaf_event = 0;  // tile pipeline: 1 = a separate event after every leaf (the full-height solve then starts ~20 us earlier)
-  int tt_fused = 0;     // tile pipeline: the chain's two one-tile GEMMs of a step in ONE launch (k_gemm.hip: tt_fused_kernel); measured: no gain, off
-  int tail_stream = 0;  // the tile pipeline's full-height GEMMs: 0 in front of the bulk on the update stream (default), 1 on a stream of their own (s_rows, a FOURTH stream)
-  double last_potrf_enqueue_ms = 0.0, last_pipe_enqueue_ms = 0.0;  // host time spent queueing the last factorisation
+  int leaf_fat_rows = 6144;  // leaf_launch: the full-tile leaf once at most this many rows remain (option leaf_algo = 2)
+  int pair_update = 1;    // two panels per trailing update (K doubled) for the far region: 0 never, 1 for Npad <= 8192, 2 always
+  int fuse_predict = 1;   // bench / compute_prediction: overlap the prediction solve with the factorisation tail
+  int small_tile_below = 256;  // panel_update: launches with fewer 128x128 tiles than this use the 64x64-tile kernel
   int timing = 0;
   int stamps = 0;  // diagnostic: device-side progress stamps per panel (gpk_get_option("stamp_panel_<p>" / "stamp_subst_<p>"), scripts/stamp_steps.py)
   unsigned long long* dstamps = nullptr;
   std::vector<unsigned long long> hstamps;
-  int pred_small_below = 300;  // predict_update: same rule for the substitution GEMMs
-  int small_tile_below = 256;  // panel_update: launches with fewer 128x128 tiles than this use the 64x64-tile kernel
-  int test_gemm_k1 = 0;   // gpk_test_gemm_nt: split K at this column into two separately stored operands
-  int pair_update = 1;    // two panels per trailing update (K doubled) for the far region: 0 never, 1 for Npad <= 8192, 2 always
-  int pipe_interleave = 0;  // 1: host submits panel p's substitutions right after panel p (0: after the whole factorisation)
-  int solve_gemm_above = 8;  // gpk_solve: more right-hand sides than this go through the blocked GEMM substitutions
-  int fuse_predict = 1;  // bench / compute_prediction: overlap the prediction solve with the factorisation tail
-  int xcd_sq = 1;              // XCD-aware 8x8-tile square order in the big GEMMs
-  int xcd_sorted = 0;          // ... with the squares of a round sorted by fill (full squares first, diagonal squares last)
-  int xcd_sq_min_tiles = 8192; // ... for launches with at least this many 128x128 tiles in the bounding rectangle
-  int ncu = 256;         // CUs available to the GEMM streams
-  int small_tile_rows = 4096;  // GEMMs with n == 128 use the 64x64 tile below this many rows... (see potrf)
+  double last_potrf_enqueue_ms = 0.0, last_pipe_enqueue_ms = 0.0;  // host time spent queueing the last factorisation
   // comm
   int rank = 0, nranks = 1;
   void* nccl = nullptr;
   std::map<std::string, StageTimer> timers;
   std::vector<hipEvent_t> ev_free;
   std::vector<hipEvent_t> ev_dep_free;  // recycled dependency events (timing disabled) of destroyed models
+  // fixed parameters of the schedule (measured once; no longer options)
+  static constexpr int nb_mid = 256, nb_big = 512, nb_small = 128;
+  static constexpr int xcd_sq_min_tiles = 8192;  // XCD-aware 8x8-tile square order for launches with at least this many tiles
+  static constexpr int solve_gemm_above = 8;     // gpk_solve: more right-hand sides than this go through the blocked GEMM substitutions
+  int pred_small_below() const { return small_tile_below == 256 ? 300 : small_tile_below; }  // predict_update: the same rule for the substitution GEMMs
+  bool nb_auto() const { return nb == 0; }
+  int outer_from() const { return 3 * outer_until; }
 };
 extern Runtime G;
 
@@ -87,17 +72,8 @@ int dev_alloc(void** p, size_t bytes);
 void dev_free(void* p, size_t bytes);
 template <class T> int dev_alloc_t(T** p, size_t n) { return dev_alloc((void**)p, n * sizeof(T)); }
 
-// One factorisation's lease on the leaf server: the server is launched when the session opens, leaf_launch() on the
-// session's chain stream posts tiles to it, and the destructor queues the quit message on that stream -- whichever way
-// the factorisation's host code ends, the server is told to leave.  Nested sessions are no-ops.
-struct LeafSession {
-  bool owner = false;
-  explicit LeafSession(hipStream_t chain);
-  ~LeafSession();
-  LeafSession(const LeafSession&) = delete;
-  LeafSession& operator=(const LeafSession&) = delete;
-};
-int leaf_launch(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, hipStream_t s);
+// rows_left: rows of the matrix from this tile on (which of the two forms of the leaf: see gpk_core.hip)
+int leaf_launch(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, hipStream_t s, int rows_left = 1 << 30);
 
 // Scratch device buffers of one API call: returned to the pool when the call ends, whichever way it ends (the update
 // stream is drained first, so nothing queued can still touch them).

@@ -26,9 +26,9 @@ int rt_require() {
 }
 
 int launch_gemm_auto(const GemmNT& g, hipStream_t s) {
-  if (G.xcd_sq && g.cyc_P == 0 && g.m % 128 == 0 && g.n % 128 == 0 && (long)(g.m / 128) * (g.n / 128) >= G.xcd_sq_min_tiles) {
+  if (g.cyc_P == 0 && g.m % 128 == 0 && g.n % 128 == 0 && (long)(g.m / 128) * (g.n / 128) >= G.xcd_sq_min_tiles) {
     GemmNT h = g;
-    h.xcd_sq = 1 | (G.xcd_sorted ? 4 : 0);
+    h.xcd_sq = 1;
     return launch_gemm_nt(h, true, s);
   }
   return launch_gemm_nt(g, true, s);
@@ -137,9 +137,8 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   gpk_model* m = new gpk_model();
   m->N = N;
   m->d = d;
-  int nb = G.nb;
+  int nb = G.nb_auto() ? G.nb_mid : G.nb / 128 * 128;
   if (nb < 128) nb = 128;
-  nb = nb / 128 * 128;
   if (growable) nb = 128;
   m->growable = growable;
   m->NB = nb;
@@ -147,8 +146,13 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   m->P = P;
   m->r = r;
   if (P > 1 && keep_k) { delete m; return gpk_set_err(-1, "keep-K models are single-GPU only"); }
+  // Block-cyclic models take the SAME panel widths by remaining size as a one-GPU model (so that every element receives
+  // the same rank-w updates in the same order: the P-rank factor is the one-GPU factor bit for bit under the default
+  // schedule too, and the bulk updates run at K = 512 where the one-GPU ones do).  An ownership block is dist_group
+  // panels of the middle width, and a whole number of the widest panels: no panel ever straddles two owners.
+  const bool auto_w = G.nb_auto() && !growable;
   const int group = (P > 1) ? std::max(1, G.dist_group) : 1;
-  m->OB = (P > 1) ? group * nb : 0;
+  m->OB = (P > 1) ? (auto_w ? round_up(group * nb, std::max(nb, G.nb_big)) : group * nb) : 0;
   m->Npad = (P > 1) ? round_up(N, m->OB) : round_up(N, GPK_T);
   if (P == 1) m->OB = m->Npad;
   m->nT = m->Npad / GPK_T;
@@ -156,13 +160,14 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   // the inner ones where the two-level schedule applies
   auto inner_width = [&](int rem) {
     int w = nb;
-    if (P == 1 && G.nb_auto && !growable) {
+    if (auto_w) {
       if (rem > G.nb_big_until + G.nb_big) w = G.nb_big;
       else if (rem <= G.nb_small_from) w = G.nb_small;
     }
+    if (P > 1) w = std::min(w, m->OB - (m->Npad - rem) % m->OB);  // (thresholds that are no multiples of the block)
     return w;
   };
-  const bool two_level = (P == 1 && !growable && G.nb_auto && G.lookahead && G.nb_outer >= 256 && m->Npad >= G.outer_from);
+  const bool two_level = (P == 1 && !growable && G.nb_auto() && G.lookahead && G.nb_outer >= 256 && m->Npad >= G.outer_from());
   size_t off = 0;
   for (int c0 = 0; c0 < m->Npad;) {
     const int rem = m->Npad - c0;
@@ -192,8 +197,7 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   m->nloc = 0;
   for (int b = 0; b < m->Npad / m->OB; ++b)
     if (b % P == r) m->nloc++;
-  // P == 1: rows of K are Npad + ldk_pad doubles apart (a power-of-two row stride aliases HBM channels: option ldk_pad)
-  m->ldk = (P > 1) ? (long)std::max(m->nloc, 1) * m->OB : (long)m->Npad + (G.ldk_pad / 2 * 2);
+  m->ldk = (P > 1) ? (long)std::max(m->nloc, 1) * m->OB : (long)m->Npad;
   m->keep_k = keep_k;
   const size_t np = m->Npad;
   int rc = 0;
@@ -256,38 +260,12 @@ int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m) {
 // sub-panels inside a panel.  L goes to its own panel-packed storage (panel p =
 // rows c0.. x w, ld = w): compact operands for every later kernel and no in-place hazard
 // in the panel solve.  Replaces np.linalg.cholesky (GPr.py:62, GPpref.py:128).
-LeafSession::LeafSession(hipStream_t chain) {
-  if (!G.leaf_server || G.leaf_chain || !chain) return;
-  if (!G.s_leaf && hipStreamCreateWithFlags(&G.s_leaf, hipStreamNonBlocking) != hipSuccess) {
-    (void)hipGetLastError();
-    G.s_leaf = nullptr;
-    return;
-  }
-  if (!G.leaf_mb) {
-    if (hipMalloc((void**)&G.leaf_mb, sizeof(LeafMailbox)) != hipSuccess || hipMemset(G.leaf_mb, 0, sizeof(LeafMailbox)) != hipSuccess) {
-      (void)hipGetLastError();
-      G.leaf_mb = nullptr;
-      return;
-    }
-    G.leaf_seq = 1;
-  }
-  if (hipMemsetAsync(&G.leaf_mb->err, 0, 4, G.s_leaf) != hipSuccess) return;
-  if (launch_leaf_server(G.leaf_mb, G.leaf_seq, G.s_leaf) != 0) return;
-  G.leaf_chain = chain;
-  owner = true;
-}
-
-LeafSession::~LeafSession() {
-  if (!owner) return;
-  // the quit message travels down the chain stream behind the last tile; if even that cannot be queued the server
-  // leaves by itself after LEAF_SERVER_LIMIT_TICKS without a message
-  (void)launch_leaf_proxy(G.leaf_mb, G.leaf_seq++, 1, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, G.leaf_chain);
-  G.leaf_chain = nullptr;
-}
-
-int leaf_launch(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, hipStream_t s) {
-  if (G.leaf_chain && s == G.leaf_chain) return launch_leaf_proxy(G.leaf_mb, G.leaf_seq++, 0, A, lda, L, ldl, Dinv, info, col0, s);
-  return launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, s);
+// rows_left: rows of the matrix from this tile on.  While much of the matrix remains the chip is full of trailing-update
+// workgroups and the leaf takes the slot-sized form (it fits where ONE of them has just finished, and the GEMM workgroup it
+// then shares the CU with pauses: gpk_internal.h); once few rows remain an empty CU is easy to find and the full-tile
+// form, alone on its CU, is the faster one (option leaf_fat_rows).  Same bits either way.
+int leaf_launch(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, hipStream_t s, int rows_left) {
+  return launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, s, rows_left <= G.leaf_fat_rows ? 1 : 0);
 }
 
 int factor_panel(gpk_model* m, int p, hipStream_t s) {
@@ -310,7 +288,7 @@ int factor_panel(gpk_model* m, int p, hipStream_t s) {
       GPK_TRY(launch_gemm_nt(g, false, s));
     }
     double* Dt = m->dDinv + (long)(cs / 128) * 128 * 128;
-    GPK_TRY(leaf_launch(Acol, ldk, Lp + (long)ro * ld + sb * 128, ld, Dt, m->dinfo, cs, s));
+    GPK_TRY(leaf_launch(Acol, ldk, Lp + (long)ro * ld + sb * 128, ld, Dt, m->dinfo, cs, s, h - ro));
     if (h - ro - 128 > 0) {
       // L[cs+128:, sub-panel] = A[cs+128:, cs:cs+128] * Dinv^T
       GemmNT g{};
@@ -502,84 +480,43 @@ static int potrf_device_paired(gpk_model* m, const std::function<int(int)>* afte
 // Where few columns remain the factorisation is a chain of dependent latency-bound kernels: per 128 columns a leaf
 // (50 us) and two or three full-height skinny GEMMs, each of which waits for CU slots next to the running update
 // (25-35 us under load instead of 8).  This schedule takes the full-height GEMMs OFF the chain.  With 128-wide panels
-// and tile rows r = p+1, p+2, ... below diagonal tile p, step p is split over three streams (event names in brackets):
-//   s_panel (critical):  leaf(p)  [leaf]                                     needs tile (p,p) final
+// and tile rows r = p+1, p+2, ... below diagonal tile p, step p is split over two streams (event names in brackets):
+//   s_panel (critical):  leaf(p)                                              needs tile (p,p) final
 //                        T(p): L(p+1,p) = A(p+1,p) Dinv(p)^T;  A(p+1,p+1) -= L(p+1,p) L(p+1,p)^T   [tt]
 //                              two one-tile GEMMs; needs LAnear(p-1)
-//   s_rows:              SOLVE(p): L(i,p) = A(i,p) Dinv(p)^T, i >= p+2       needs leaf(p)              [panel]
-//                        LAnear(p): A(i, p+1..p+2) -= L(i,p) L(p+1..p+2, p)^T, i >= p+2   needs T(p)    [near]
-//                        LAfar(p):  A(i, p+3)      -= L(i,p) L(p+3,p)^T,       i >= p+3   needs REST(p-1)
-//   s_main:              REST(p): lower square from tile (p+4,p+4), the bulk   needs SOLVE(p)             [rest]
+//   s_main, in front of the bulk:
+//                        SOLVE(p): L(i,p) = A(i,p) Dinv(p)^T, i >= p+2       needs T(p) (only the leaf, really: one event
+//                                                                             per step instead of two)            [panel]
+//                        LAnear(p): A(i, p+1..p+2) -= L(i,p) L(p+1..p+2, p)^T, i >= p+2                            [near]
+//                        LAfar(p):  A(i, p+3)      -= L(i,p) L(p+3,p)^T,       i >= p+3   (after REST(p-1): stream order)
+//                        REST(p): lower square from tile (p+4,p+4), the bulk
 // so the chain per step is leaf + two one-tile kernels, and a column is written, in this order, by REST (up to four
-// steps earlier), LAfar, LAnear and T: every hazard is covered by stream order on s_rows plus the three waits above.
+// steps earlier), LAfar, LAnear and T: every hazard is covered by stream order on s_main plus the two waits above.
 // Each element receives the same rank-128 updates in the same order as in the panel-level schedule with 128-wide
 // panels, so the factor is bit-identical to it (tests).  `ev_prev_rest`: what plays REST(p_first - 1).
+// What was tried on top of this and dropped (a stream of its own for the full-height GEMMs, the two one-tile GEMMs in one
+// launch, flag-chained steps without event packets, a resident leaf server): DESIGN.md section 6.
 static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const std::function<int(int)>* after_panel) {
-  hipStream_t sm = G.s_main, sc = G.s_panel, sr = (G.tail_stream && G.s_rows) ? G.s_rows : G.s_main;
+  hipStream_t sm = G.s_main, sc = G.s_panel;
   const int nP = m->nP, np_ = m->Npad;
   const long ldk = m->ldk;
   hipEvent_t* ev_panel = m->ev.data();
   hipEvent_t* ev_leaf = m->ev.data() + 3 * nP + 6;
   hipEvent_t* ev_tt = m->ev.data() + 4 * nP + 6;
   hipEvent_t* ev_near = m->ev.data() + 5 * nP + 6;
-  hipEvent_t* ev_rest = m->ev.data() + 6 * nP + 6;
-  GPK_HIP(hipStreamWaitEvent(sr, ev_prev_rest, 0));  // s_rows joins here; its first kernels also wait for a leaf
-  unsigned tt_count = 0;
-  const bool flags = G.tail_flags && sr == sm && G.dflags && nP <= 1024;
-  if (flags) {  // the caller's look-ahead work on the chain stream precedes the first T step, which now runs on the update stream
-    GPK_HIP(hipEventRecord(ev_tt[p_first], sc));
-    GPK_HIP(hipStreamWaitEvent(sm, ev_tt[p_first], 0));
-  }
-  // flag-chained mode: leaf kernel of step q on the chain stream and its T kernel on the update stream.  They are queued
-  // right behind LAnear(q-1) -- all the T step needs from the update stream -- and IN FRONT of LAfar(q-1) / REST(q-1), so
-  // that the T kernel is resident and spinning when its leaf ends instead of queueing behind a step's worth of launches.
-  auto enqueue_flag_step = [&](int q) -> int {
-    const int qc0 = m->pc0[q], qh = np_ - qc0;
-    const long qld = m->pld[q];
-    double* qLp = m->Lpanel(q);
-    double* qA = m->dK + (long)qc0 * ldk + qc0;
-    double* qD = m->dDinv + (long)(qc0 / 128) * 128 * 128;
-    unsigned* F = G.dflags + 4 * (size_t)q;  // leaf flag, tt flag, two counters (zeroed with dinfo)
-    GPK_TRY(launch_leaf_flag(qA, ldk, qLp, qld, qD, m->dinfo, qc0, q > p_first ? F - 4 + 1 : nullptr, F, sc));
-    if (qh <= 128) {
-      GPK_HIP(hipEventRecord(ev_leaf[q], sc));
-      return 0;
-    }
-    GemmNT t1{};  // L(q+1,q) = A(q+1,q) Dinv^T
-    t1.A = qA + (long)128 * ldk; t1.lda = ldk;
-    t1.B = qD; t1.ldb = 128;
-    t1.C = qLp + (long)128 * qld; t1.ldc = qld;
-    t1.m = 128; t1.n = 128; t1.k = 128; t1.sub = 0;
-    GemmNT t2{};  // A(q+1,q+1) -= L(q+1,q) L(q+1,q)^T
-    t2.A = qLp + (long)128 * qld; t2.lda = qld;
-    t2.B = t2.A; t2.ldb = qld;
-    t2.C = qA + (long)128 * ldk + 128; t2.ldc = ldk;
-    t2.m = 128; t2.n = 128; t2.k = 128; t2.sub = 1; t2.lower = 1;
-    return launch_tt_flag(t1, t2, F, F + 2, F + 1, m->dinfo, sm);
-  };
-  if (flags) GPK_TRY(enqueue_flag_step(p_first));
+  GPK_HIP(hipStreamWaitEvent(sm, ev_prev_rest, 0));
   for (int p = p_first; p < nP; ++p) {
     const int c0 = m->pc0[p], h = np_ - c0;
     const long ld = m->pld[p];
     double* Lp = m->Lpanel(p);
     double* Acol = m->dK + (long)c0 * ldk + c0;
     double* Dt = m->dDinv + (long)(c0 / 128) * 128 * 128;
-    hipEvent_t rest_before = (p > p_first) ? ev_rest[p - 1] : ev_prev_rest;
     // ---- critical stream.  One event per step: `tt` after the two one-tile GEMMs (or `leaf` for the last tile, which has
-    // none).  The full-height solve only needs the leaf, but it waits for `tt` as well: an event packet on the chain
-    // stream costs ~5 us of a ~85 us step, and the solve is never what the chain waits for next (near(p) is due one
-    // leaf later).  G.tail_leaf_event = 1 restores the separate leaf event.
-    const bool leaf_ev = G.tail_leaf_event || h <= 128;
-    // FLAG-CHAINED steps (option tail_flags): the chain stream carries nothing but leaf kernels, each of which spins until
-    // the previous step's T kernel has set its flag; that T kernel sits on the update stream -- behind LAnear(p-1), which
-    // it needs, by stream order -- and spins until its leaf has set the leaf flag.  No event packet, no dependent launch
-    // on the chain (k_gemm.hip: tt_flag_kernel, k_potf2.hip: leaf_flag_kernel; every wait bounded).  Step p's pair was
-    // queued by enqueue_flag_step (before the loop, or behind LAnear(p-1) below).
-    if (!flags) {
-    GPK_TRY(leaf_launch(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, sc));
-    if (leaf_ev) GPK_HIP(hipEventRecord(ev_leaf[p], sc));
-    }
-    if (h > 128 && !flags) {
+    // none): an event packet on the chain stream costs ~5 us of a ~85 us step, and the full-height solve is never what the
+    // chain waits for next (near(p) is due one leaf later).
+    GPK_TRY(leaf_launch(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, sc, h));
+    if (h <= 128) GPK_HIP(hipEventRecord(ev_leaf[p], sc));
+    if (h > 128) {
       if (p > p_first) GPK_HIP(hipStreamWaitEvent(sc, ev_near[p - 1], 0));
       GemmNT t1{};  // L(p+1,p) = A(p+1,p) Dinv^T
       t1.A = Acol + (long)128 * ldk; t1.lda = ldk;
@@ -591,28 +528,22 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       t2.B = t2.A; t2.ldb = ld;
       t2.C = Acol + (long)128 * ldk + 128; t2.ldc = ldk;
       t2.m = 128; t2.n = 128; t2.k = 128; t2.sub = 1; t2.lower = 1;
-      if (G.tt_fused) {  // both in one launch (dinfo[2] counts T1's blocks; zeroed with dinfo at the start of the factorisation)
-        tt_count += 4;
-        GPK_TRY(launch_tt_fused(t1, t2, reinterpret_cast<unsigned*>(m->dinfo + 2), tt_count, m->dinfo, sc));
-      } else {
-        GPK_TRY(launch_gemm_nt(t1, false, sc));
-        GPK_TRY(launch_gemm_nt(t2, false, sc));
-      }
+      GPK_TRY(launch_gemm_nt(t1, false, sc));
+      GPK_TRY(launch_gemm_nt(t2, false, sc));
       GPK_HIP(hipEventRecord(ev_tt[p], sc));
     }
-    // ---- full-height panel GEMMs
-    if (!flags || h <= 128) GPK_HIP(hipStreamWaitEvent(sr, leaf_ev ? ev_leaf[p] : ev_tt[p], 0));
+    // ---- full-height panel GEMMs, in front of the bulk on the update stream
+    GPK_HIP(hipStreamWaitEvent(sm, h <= 128 ? ev_leaf[p] : ev_tt[p], 0));
     if (h > 256) {
       GemmNT g{};  // SOLVE(p): rows from tile p+2
       g.A = Acol + (long)256 * ldk; g.lda = ldk;
       g.B = Dt; g.ldb = 128;
       g.C = Lp + (long)256 * ld; g.ldc = ld;
       g.m = h - 256; g.n = 128; g.k = 128; g.sub = 0;
-      GPK_TRY(launch_gemm_nt(g, false, sr));
+      GPK_TRY(launch_gemm_nt(g, false, sm));
     }
-    if (h > 128 && leaf_ev && !flags) GPK_HIP(hipStreamWaitEvent(sr, ev_tt[p], 0));
-    GPK_HIP(hipEventRecord(ev_panel[p], sr));  // every row of panel p is in place
-    if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sr));
+    GPK_HIP(hipEventRecord(ev_panel[p], sm));  // every row of panel p is in place
+    if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sm));
     if (after_panel) GPK_TRY((*after_panel)(p));
     if (h > 256) {
       GemmNT g{};  // LAnear(p): tile columns p+1, p+2, rows from tile p+2
@@ -620,21 +551,18 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       g.B = Lp + (long)128 * ld; g.ldb = ld;
       g.C = Acol + (long)256 * ldk + 128; g.ldc = ldk;
       g.m = h - 256; g.n = std::min(256, h - 128); g.k = 128; g.sub = 1;
-      GPK_TRY(launch_gemm_nt(g, false, sr));
+      GPK_TRY(launch_gemm_nt(g, false, sm));
     }
-    GPK_HIP(hipEventRecord(ev_near[p], sr));
-    if (flags && p + 1 < nP) GPK_TRY(enqueue_flag_step(p + 1));
+    GPK_HIP(hipEventRecord(ev_near[p], sm));
     if (h > 384) {
-      if (sr != sm) GPK_HIP(hipStreamWaitEvent(sr, rest_before, 0));  // (same stream: stream order; an event packet costs ~5 us)
       GemmNT g{};  // LAfar(p): tile column p+3, rows from tile p+3
       g.A = Lp + (long)384 * ld; g.lda = ld;
       g.B = g.A; g.ldb = ld;
       g.C = Acol + (long)384 * ldk + 384; g.ldc = ldk;
       g.m = h - 384; g.n = 128; g.k = 128; g.sub = 1; g.lower = 1;
-      GPK_TRY(launch_gemm_nt(g, false, sr));
+      GPK_TRY(launch_gemm_nt(g, false, sm));
     }
     // ---- bulk
-    if (sr != sm) GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
     if (h > 512) {
       const int r1 = c0 + 512;
       const long nt = (np_ - r1) / 128;
@@ -643,18 +571,14 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       GPK_TRY(panel_update(m, p, r1, r1, np_ - r1, 1, sm));
       timer_end(tname, sm);
     }
-    if (sr != sm) GPK_HIP(hipEventRecord(ev_rest[p], sm));
   }
-  // join: everything after potrf runs on s_main
-  GPK_HIP(hipStreamWaitEvent(sm, ev_panel[nP - 1], 0));
-  GPK_HIP(hipStreamWaitEvent(sm, ev_near[nP - 1], 0));
-  GPK_HIP(hipStreamWaitEvent(sm, ev_leaf[nP - 1], 0));  // the last tile has no T step: its leaf event is always recorded
+  // join: everything after potrf runs on s_main (which has waited for every step's chain event)
   return 0;
 }
 
 // first outer panel of the tile-pipeline tail (nO: no tail): from there on every panel is a single 128-wide one
 static int tail_first_panel(const gpk_model* m) {
-  if (!G.tail_rows || (G.tail_stream && !G.s_rows) || m->P != 1) return m->nO;
+  if (!G.tail_rows || m->P != 1) return m->nO;
   int o = m->nO;
   while (o > 0 && m->ow[o - 1] == 128 && m->oend[o - 1] - m->ofirst[o - 1] == 1 && m->Npad - m->oc0[o - 1] <= G.tail_rows) --o;
   if (m->nO - o < 4) return m->nO;  // not worth a stream hand-over
@@ -672,13 +596,6 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
     return potrf_group(&one, 1);
   }
   GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
-  if (G.tail_flags) {
-    if (!G.dflags && hipMalloc((void**)&G.dflags, 4 * 1024 * sizeof(unsigned)) != hipSuccess) {
-      (void)hipGetLastError();
-      G.dflags = nullptr;
-    }
-    if (G.dflags) GPK_HIP(hipMemsetAsync(G.dflags, 0, 4 * 1024 * sizeof(unsigned), sm));
-  }
   const int nP = m->nP;
   g_potrf_lookahead_used = 0;
   if (!G.lookahead || nP < 3) {
@@ -698,7 +615,6 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   // run faster (50 vs 44.5 TFLOP/s) but the three narrow updates per pair it needs (16 % of the flops) cost more
   // than that (N = 16384: 38.1-38.5 vs 36.9-37.05 ms, N = 32768: 241.8 vs 231.9).  1: only up to 8192, 2: always.
   g_potrf_tail_from = -1;
-  LeafSession leaf_session(sp);  // the panel chain's leaves go to the resident server from here on
   if (nP >= 6 && m->nO == nP && tail_first_panel(m) == m->nO && (G.pair_update == 2 || (G.pair_update == 1 && m->Npad <= 8192)))
     return potrf_device_paired(m, after_panel);
   GPK_TRY(model_events(m, 7 * nP + 8));
@@ -1109,8 +1025,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   // factorisation: the forward substitution w = L^-1 y (two tiny kernels per panel) and, for a fused
   // fit+predict, the forward substitution of the prediction.  While the trailing updates saturate the
   // chip this merely re-orders work; in the latency-bound tail of the factorisation it fills idle CUs.
-  // The host submits panel p's substitutions right after panel p itself (hook below), not after the whole
-  // factorisation.
+  // (The host queues them after the whole factorisation; queueing panel p's right after panel p was measured: no gain.)
   const bool pipelined = G.s_pred && m->P == 1 && G.fuse_predict && G.lookahead && m->nP >= 3 && (m->has_y || fuse);
   bool fused_done = false;
   hipStream_t sq = G.s_pred;
@@ -1147,7 +1062,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   }
   if (G.stamps && G.dstamps) GPK_HIP(hipMemsetAsync(G.dstamps, 0, 1024 * 8, s));
   const auto host_t0 = std::chrono::steady_clock::now();
-  GPK_TRY(potrf_device(m, (pipelined && G.pipe_interleave) ? &hook : nullptr));
+  GPK_TRY(potrf_device(m));
   G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   timer_end("potrf", s);
   // s_main has joined the last panel: the log-determinant can run while the substitution stream finishes
@@ -1155,16 +1070,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   const auto host_t1 = std::chrono::steady_clock::now();
   if (pipelined) {
     if (!g_potrf_lookahead_used) return gpk_set_err(-1, "internal: pipelined substitutions without look-ahead");
-    if (!G.pipe_interleave) {
-      if (G.pred_gate_rows > 0) {
-        // experiment: hold the substitutions back until only pred_gate_rows columns remain (the chain-bound tail,
-        // where the chip has spare capacity), so that the bulk updates run alone
-        int pg = 0;
-        while (pg < m->nP && np_ - m->pc0[pg] > G.pred_gate_rows) ++pg;
-        if (pg > 0 && pg < m->nP) GPK_HIP(hipStreamWaitEvent(sq, m->ev[pg], 0));
-      }
-      for (int p = 0; p < m->nP; ++p) GPK_TRY(hook(p));
-    }
+    for (int p = 0; p < m->nP; ++p) GPK_TRY(hook(p));
     if (fuse) {
       timer_end("predict", sq);
       fused_done = true;
@@ -1204,7 +1110,6 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   if (G.stamps && G.dstamps) GPK_HIP(hipMemcpyAsync(G.hstamps.data(), G.dstamps, 1024 * 8, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipStreamSynchronize(s));
   m->info = hinfo;
-  if (hinfo >= LEAF_SERVER_INFO_POISON) return gpk_set_err(-3, "fit: the resident leaf server did not answer (mailbox time-out)");
   if (hinfo > 0) return hinfo > m->N ? m->N : hinfo;
   m->factored = true;
   m->logdet = hs[0];
@@ -1254,7 +1159,7 @@ static int predict_update(gpk_model* m, int p, int Mpad, int cg0, int ncols, dou
   g.C = dR + cg0; g.ldc = np_;
   g.m = Mpad; g.n = ncols; g.k = w; g.sub = 1;
   // few 128x128 tiles (the look-ahead block column): 64x64 tiles put 4x as many CUs on the critical path
-  if ((long)(Mpad / 128) * (ncols / 128) < G.pred_small_below) return launch_gemm_nt(g, false, s);
+  if ((long)(Mpad / 128) * (ncols / 128) < G.pred_small_below()) return launch_gemm_nt(g, false, s);
   return launch_gemm_auto(g, s);
 }
 // the same with a whole outer panel: R[:, cg0 : cg0+ncols] -= V[:, outer o] * Lo[(cg0-oc0) : +ncols, :]^T  (K = ow[o])
@@ -1267,7 +1172,7 @@ static int predict_outer_update(gpk_model* m, int o, int Mpad, int cg0, int ncol
   g.B = m->Lo(o) + (long)(cg0 - c0) * W; g.ldb = W;
   g.C = dR + cg0; g.ldc = np_;
   g.m = Mpad; g.n = ncols; g.k = W; g.sub = 1;
-  if ((long)(Mpad / 128) * (ncols / 128) < G.pred_small_below) return launch_gemm_nt(g, false, s);
+  if ((long)(Mpad / 128) * (ncols / 128) < G.pred_small_below()) return launch_gemm_nt(g, false, s);
   return launch_gemm_auto(g, s);
 }
 // Everything inner panel p contributes to the row substitution, in the two-level order: its diagonal solve, its
@@ -1370,7 +1275,7 @@ int rows_backward_solve(gpk_model* m, int Mpad, double* dR, double* dY, const do
       g.B = dU + c0; g.ldb = np_;
       g.C = dR; g.ldc = np_;
       g.m = Mpad; g.n = c0; g.k = w; g.sub = 1;
-      if ((long)(Mpad / 128) * (c0 / 128) < G.pred_small_below) GPK_TRY(launch_gemm_nt(g, false, s));
+      if ((long)(Mpad / 128) * (c0 / 128) < G.pred_small_below()) GPK_TRY(launch_gemm_nt(g, false, s));
       else GPK_TRY(launch_gemm_auto(g, s));
     }
   }

@@ -32,6 +32,16 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ---------------------------------------------------------------- GEMM (NT)
 // C[m x n] (op)= A[m x k] * B[n x k]^T, all row-major fp64, MFMA 16x16x4 f64.
 // m, n multiples of the block tile (128 or 64), k multiple of 16.
+// "Polite co-residency" (no CU is reserved for the latency-critical leaf any more): a table of guest counters, one per
+// physical CU (index = XCC_ID * 256 + HW_ID bits [15:8]: se, sh, cu), in device memory.  The leaf raises its CU's counter
+// while it runs; wave 0 of every 8-wave GEMM workgroup reads its CU's counter once per K-slab (a load that rides on the
+// slab's own vmcnt wait) and, while it is non-zero, sleeps -- the workgroup then stops at its next barrier -- so the leaf has
+// the CU's fp64 pipe to itself although it only ever got the slot one finished GEMM workgroup left.  Bounded: a GEMM wave
+// sleeps at most GPK_GUEST_LIMIT_TICKS of the 100 MHz clock per visit.
+#define GPK_GUEST_SLOTS 2048
+constexpr unsigned long long GPK_GUEST_LIMIT_TICKS = 30000ull;  // 300 us
+extern unsigned* g_cu_guest;  // nullptr: nothing polls, nothing announces (k_gemm.hip)
+
 struct GemmNT {
   const double* A; long lda;
   const double* B; long ldb;
@@ -50,52 +60,21 @@ struct GemmNT {
   const double* A2; long lda2;
   const double* B2; long ldb2;
   int k1;
+  const unsigned* guest;  // the guest table (filled in by launch_gemm_nt; nullptr = do not poll)
+  unsigned long long* trace;  // timing builds only (make DBG=1): per-workgroup time stamps
 };
-// tile128 = true: 128x128 block tile (4x4 MFMA tiles per wave); false: 64x64 (2x2 per wave).
+// tile128 = true: the 8-wave 128x128-tile kernel (LDS-DMA staged); false: the 64x64-tile kernel (4 waves, 2x2 MFMA tiles each).
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s);
 // the 8-wave kernel, with the XCD-aware tile order for the largest updates
 int launch_gemm_auto(const GemmNT& g, hipStream_t s);
-// T1 (one full 128x128 tile) and T2 (one lower 128x128 tile that reads T1's result) of a tile-pipeline step in one launch;
-// *ctr must have been `target - 4` when the launch starts (it counts T1's four blocks)
-int launch_tt_fused(const GemmNT& t1, const GemmNT& t2, unsigned* ctr, unsigned target, int* info, hipStream_t s);
-// flag-chained tile pipeline (potrf_tail, option tail_flags): the T step launched on the update stream ahead of its leaf,
-// and the leaf kernel that waits for the previous T step's flag.  ctr2: two zeroed words, flags: zeroed words.
-int launch_tt_flag(const GemmNT& t1, const GemmNT& t2, const unsigned* leaf_flag, unsigned* ctr2, unsigned* tt_flag, int* info, hipStream_t s);
-int launch_leaf_flag(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, const unsigned* wait_flag,
-                     unsigned* set_flag, hipStream_t s);
-
 // ---------------------------------------------------------------- leaf factor
 // Factor the 128x128 diagonal tile A (lda) -> L tile (ldl, strict upper zeroed) and
 // Dinv = inv(L) (dense 128x128, ld 128, strict upper zeroed).  *info gets
 // (col0 + j + 1) of the first non-positive pivot (only if it is still 0).
+// fat: the caller expects an EMPTY CU to be easy to find (little else queued): the 1024-thread / 132 KiB form, which shares
+// its CU with nobody, instead of the slot-sized one (k_potf2.hip).  Same bits either way.
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info,
-                           int col0, int n_valid, hipStream_t s);
-
-// The resident leaf server.  One 1024-thread workgroup (the leaf's own shape: a whole CU) is launched once per
-// factorisation on a stream of its own and stays on its CU; the panel chain reaches it through a mailbox in HBM: a
-// one-wave PROXY kernel in the chain stream posts the tile and spins until the server reports it done, so stream order
-// and every dependency of the chain stay what they are with a direct launch.  What it buys: the leaf needs an EMPTY
-// CU (132 KiB of LDS), which beside thousands of queued GEMM workgroups only a CU mask on the update stream could
-// guarantee -- and a CU-masked queue places its waves unevenly over the SIMDs (scripts/mfma_pinned.py: 5/3 and 6/2
-// waves per SIMD instead of 4/4), which costs the bulk update ~10 %.  With the server nothing is masked.
-// Every wait is bounded (LEAF_SERVER_LIMIT_TICKS of the 100 MHz clock): a server that hears nothing exits, a proxy
-// whose server does not answer gives up, both raise `err`, and the proxy poisons *info (LEAF_SERVER_INFO_POISON).
-struct LeafMailbox {
-  const double* A; long lda;
-  double* L; long ldl;
-  double* Dinv;
-  int* info;
-  int col0, op;              // op 0: factor a tile, 1: quit
-  unsigned pad0[18];
-  unsigned go;  unsigned pad1[31];    // sequence number of the posted task (own 128-byte line)
-  unsigned done; unsigned pad2[31];   // sequence number of the last finished task
-  unsigned err;  unsigned pad3[31];   // 1: the server timed out, 2: a proxy timed out
-};
-constexpr unsigned long long LEAF_SERVER_LIMIT_TICKS = 500000000ull;  // 5 s
-constexpr int LEAF_SERVER_INFO_POISON = 0x40000000;
-int launch_leaf_server(LeafMailbox* mb, unsigned first_seq, hipStream_t s);
-int launch_leaf_proxy(LeafMailbox* mb, unsigned seq, int op, const double* A, long lda, double* L, long ldl,
-                      double* Dinv, int* info, int col0, hipStream_t s);
+                           int col0, int n_valid, hipStream_t s, int fat = 0);
 
 // ---------------------------------------------------------------- builders
 struct SEParams {

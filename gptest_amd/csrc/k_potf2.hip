@@ -2,17 +2,14 @@
 // factor (the inverse turns every panel solve into an MFMA GEMM).  Replaces the unblocked
 // interior of LAPACK potrf behind np.linalg.cholesky (GPr.py:62, GPpref.py:128).
 //
-// One workgroup of 1024 threads (16 waves) on one CU.
-//  1. Elimination with the WHOLE tile in registers: thread (i, kg) owns row i and the column
-//     pairs {16*q + 2*kg, +1 | q = 0..7} (cyclic pairs: balanced until the last columns, and
-//     the published column is read back as 16-byte pairs).  Per column j the owners publish
-//     column j and 1/pivot into a double-buffered LDS vector, ONE barrier, then every thread
-//     applies the rank-1 update to its registers with no per-lane predicate: the full symmetric
-//     tile is updated, the lower triangle is bit-for-bit what a masked update would give.
-//     Square-root-free: column j and pivot j are final after step j, L = S*diag(1/sqrt(piv))
-//     is applied once at the end.
-//  2. In-place inverse of L in LDS (128 x 129 doubles, odd stride = conflict-free column
-//     walks): the 16x16 diagonal blocks by per-wave forward substitution, then recursive doubling
+// One workgroup on one CU, two forms of the SAME blocked algorithm (bit-identical results):
+//   * the slot-sized leaf (512 threads, 76.6 KiB block-triangular LDS image): fits the slot one finished trailing-update
+//     workgroup frees, announces itself in the guest table so that the GEMM workgroups on its CU pause (gpk_internal.h);
+//   * the full-tile leaf (1024 threads, 132 KiB): alone on its CU, 2 us faster, for when an empty CU is easy to find.
+//  1. Blocked elimination, 8 steps of 16 columns on the tile in LDS: the 16x16 diagonal block is factored by one wave inside
+//     ONE MFMA accumulator, the rows below solve against it by substitution (one thread per row), the trailing 16x16 blocks
+//     take the rank-16 update on the matrix pipe while wave 0 already factors the next diagonal block.
+//  2. In-place inverse of L: the 16x16 diagonal blocks by per-wave forward substitution, then recursive doubling
 //     X21 = -X22*(L21*X11) for block sizes 16/32/64 with v_mfma_f64_16x16x4_f64 reading its fragments
 //     straight from the tile.
 #include "gpk_internal.h"
@@ -28,7 +25,7 @@ static __device__ __forceinline__ double readlane_d(double v, int l) {
 
 #define PLD 129
 #define LEAF_STAMP(k) do { if ((dbg_skip & 8) && tid == 0) info[k] = (int)__builtin_amdgcn_s_memrealtime(); } while (0)
-#define CBLD 132  // published column: 128 values + 1/pivot at [128], padded to a multiple of 2
+
 
 // Factor of the 16x16 diagonal block at column c0 of the LDS tile, executed by ONE wave, rank-4 updates on the
 // matrix pipe.  The 16x16 block lives in ONE accumulator (C/D layout:
@@ -106,132 +103,21 @@ static __device__ __forceinline__ void leaf_update_tile(double* S, int c0, int t
   for (int r = 0; r < 4; ++r) S[(RI + fg + 4 * r) * PLD + RJ + fr] = acc[r];
 }
 
-// The leaf's work on one tile.  S (128 * PLD + 2 * CBLD + 128 doubles, 16-byte aligned), rinvb (16) and failflag live
-// in the calling kernel's LDS: the one-shot kernel below and the resident leaf server share this body.
-// COH: the tile is read and the results are written THROUGH the caches (agent-scope accesses): the resident server
-// neither invalidates nor writes back its XCD's L2 per tile, which the other kernels on that XCD would pay for.
-template <bool COH> static __device__ __forceinline__ double leaf_ldg(const double* p) {
-  return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-template <bool COH> static __device__ __forceinline__ void leaf_stg(double* p, double v) {
-  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-template <int ALGO, bool COH = false>  // 0: column-by-column elimination in registers; 1: blocked elimination (default)
+// The full-tile leaf's work on one tile.  S (128 * PLD doubles, 16-byte aligned), rinvb (16) and failflag live in the
+// calling kernel's LDS.  dbg_skip (timing only): 1 no elimination, 2 no inverse, 8 phase stamps in info[3..7], 16 no panel
+// solve, 32 no trailing updates, 64 no diagonal blocks.
 static __device__ __forceinline__ void leaf_body(const double* __restrict__ A, long lda, double* __restrict__ L, long ldl,
                                                  double* __restrict__ Dinv, int* info, int col0, int dbg_skip,
                                                  double* S, double* rinvb, int& failflag, const int tid) {
-  constexpr int algo = ALGO;
-  double* colbuf = S + 128 * PLD;       // [2][CBLD]; 128*129 and CBLD are even -> 16-byte aligned pair reads
-  double* pivbuf = colbuf + 2 * CBLD;   // [128] pivots
   LEAF_STAMP(3);
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int i = e >> 7, j = e & 127;
-    S[i * PLD + j] = leaf_ldg<COH>(A + (long)i * lda + j);
+    S[i * PLD + j] = A[(long)i * lda + j];
   }
   __syncthreads();
   LEAF_STAMP(4);
-
-  if (algo == 0) {
-  const int i = tid & 127;
-  const int kg = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform -> scalar branches below
-  double a[8][2];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    a[q][0] = S[i * PLD + 16 * q + 2 * kg];
-    a[q][1] = S[i * PLD + 16 * q + 2 * kg + 1];
-  }
-  int fail = 0;
-  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#pragma unroll
-  for (int jq = 0; jq < 8; ++jq) {
-    if (dbg_skip & 1) break;
-#pragma nounroll
-    for (int jkg = 0; jkg < 8; ++jkg) {  // NOT unrolled: the fully unrolled body overflows the instruction cache
-#pragma unroll
-      for (int jh = 0; jh < 2; ++jh) {
-        const int j = 16 * jq + 2 * jkg + jh;
-        double* cb = colbuf + (j & 1) * CBLD;
-        if (kg == jkg) {
-          const double v = a[jq][jh];
-          cb[i] = v;
-          if (i == j) {
-            const bool ok = (v > 1.0e-300) && (v < 1.0e300);
-            // reciprocal on the critical path of every column: v_rcp_f64 + two Newton steps (~1 ulp)
-            double rcp = __builtin_amdgcn_rcp(v);
-            rcp = rcp * (2.0 - v * rcp);
-            rcp = rcp * (2.0 - v * rcp);
-            cb[128] = ok ? rcp : -1.0;  // non-positive / NaN / Inf pivot -> flagged to everyone
-            pivbuf[j] = v;
-          }
-        }
-        __syncthreads();
-        // issue every LDS read of this step back to back (one latency, not three), then test the pivot
-        const double rinv = cb[128];
-        const double ci = cb[i];
-        d2 cq[8];
-#pragma unroll
-        for (int q = jq; q < 8; ++q) cq[q] = *reinterpret_cast<const d2*>(cb + 16 * q + 2 * kg);
-        if (!(rinv > 0.0)) {  // block-uniform
-          fail = j + 1;
-          break;
-        }
-        const double lij = ci * rinv;
-        // columns of this thread in block jq that are right of column j (wave-uniform tests)
-        if (kg > jkg) {
-          a[jq][0] -= lij * cq[jq].x;
-          a[jq][1] -= lij * cq[jq].y;
-        } else if (kg == jkg && jh == 0) {
-          a[jq][1] -= lij * cq[jq].y;  // column j+1 is the second half of this thread's own pair
-        }
-#pragma unroll
-        for (int q = jq + 1; q < 8; ++q) {
-          a[q][0] -= lij * cq[q].x;
-          a[q][1] -= lij * cq[q].y;
-        }
-      }
-      if (fail) break;
-    }
-    if (fail) break;
-  }
-  __syncthreads();
-  if ((dbg_skip & 8) && tid == 0) {  // diagnostic build path only: cycles / 100 MHz ticks of the elimination
-    info[1] = (int)(__builtin_amdgcn_s_memtime() - st_c0);
-    info[2] = (int)(__builtin_amdgcn_s_memrealtime() - st_r0);
-  }
-  if (fail) {
-    if (tid == 0) atomicCAS(info, 0, col0 + fail);
-    // keep downstream kernels on finite data: emit identity factors for this tile
-    for (int e = tid; e < 128 * 128; e += 1024) {
-      const int ii = e >> 7, jj = e & 127;
-      const double v = (ii == jj) ? 1.0 : 0.0;
-      leaf_stg<COH>(L + (long)ii * ldl + jj, v);
-      leaf_stg<COH>(Dinv + ii * 128 + jj, v);
-    }
-    return;
-  }
-  // ---- scale: L[i][k] = a / sqrt(piv_k), L[k][k] = sqrt(piv_k), zero above; back to LDS
-  double* isq = colbuf;  // [128] 1/sqrt(piv), computed once per column
-  if (tid < 128) {
-    const double dk = sqrt(pivbuf[tid]);
-    pivbuf[tid] = dk;
-    isq[tid] = 1.0 / dk;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = 16 * q + 2 * kg + h;
-      double x = 0.0;
-      if (k < i) x = a[q][h] * isq[k];
-      if (k == i) x = pivbuf[k];
-      S[i * PLD + k] = x;
-    }
-  }
-  __syncthreads();
-  } else {
-    // ---- blocked elimination (algo 1): 8 steps of 16 columns, the tile stays in LDS.
+  {
+    // ---- blocked elimination: 8 steps of 16 columns, the tile stays in LDS.
     //  (1) wave 0 factors the 16x16 diagonal block in one MFMA accumulator (leaf_diag_block_mfma: no barrier and no
     //      LDS round trip inside the 16 sequential columns), rsqrt + Newton on the pivot;
     //  (2) the rows below solve against it by substitution, one thread per row, L11 read as LDS broadcasts;
@@ -283,8 +169,8 @@ static __device__ __forceinline__ void leaf_body(const double* __restrict__ A, l
       for (int e = tid; e < 128 * 128; e += 1024) {
         const int ii = e >> 7, jj = e & 127;
         const double v = (ii == jj) ? 1.0 : 0.0;
-        leaf_stg<COH>(L + (long)ii * ldl + jj, v);
-        leaf_stg<COH>(Dinv + ii * 128 + jj, v);
+        L[(long)ii * ldl + jj] = v;
+        Dinv[ii * 128 + jj] = v;
       }
       return;
     }
@@ -296,7 +182,7 @@ static __device__ __forceinline__ void leaf_body(const double* __restrict__ A, l
   }
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int ii = e >> 7, jj = e & 127;
-    leaf_stg<COH>(L + (long)ii * ldl + jj, S[ii * PLD + jj]);
+    L[(long)ii * ldl + jj] = S[ii * PLD + jj];
   }
   __syncthreads();
   if (tid < 128) S[tid * PLD + tid] = 1.0 / S[tid * PLD + tid];
@@ -375,14 +261,14 @@ static __device__ __forceinline__ void leaf_body(const double* __restrict__ A, l
   LEAF_STAMP(6);
   for (int e = tid; e < 128 * 128; e += 1024) {
     const int ii = e >> 7, jj = e & 127;
-    leaf_stg<COH>(Dinv + e, (jj <= ii) ? S[ii * PLD + jj] : 0.0);
+    Dinv[e] = (jj <= ii) ? S[ii * PLD + jj] : 0.0;
   }
   LEAF_STAMP(7);
 }
 
 
 // ---------------------------------------------------------------- the slot-sized leaf (default)
-// The same blocked algorithm -- operation for operation, so the factor and its inverse are BIT-IDENTICAL to leaf_body<1> --
+// The same blocked algorithm -- operation for operation, so the factor and its inverse are BIT-IDENTICAL to leaf_body --
 // in a workgroup that fits the slot ONE finished trailing-update workgroup frees on a CU: 8 waves of <= 128 VGPRs and 76.6 KiB
 // of LDS (the update kernel holds 64 KiB per workgroup, two per CU, of 160 KiB).  The 1024-thread / 132 KiB form needs an
 // EMPTY CU, which beside thousands of queued update workgroups only a CU mask on the update stream could provide, and a
@@ -420,12 +306,16 @@ static __device__ __forceinline__ void leaf_body_tri(const double* __restrict__ 
   const int fr = lane & 15, fg = lane >> 4;
   LEAF_STAMP(3);
   // ---- load the lower blocks: block row I is 16 rows of 16 (I + 1) contiguous doubles
+  // (16-byte loads: A is 16-byte aligned with an even leading dimension, as every operand of the GEMM kernels)
 #pragma unroll
   for (int I = 0; I < 8; ++I) {
-    const int rl = 16 * (I + 1);
+    const int rl = 8 * (I + 1);  // pairs per row
     for (int e = tid; e < 16 * rl; e += 512) {
-      const int r = e / rl, c = e - r * rl;
-      S[tri_base(I, c >> 4) + r * TLD + (c & 15)] = A[(long)(16 * I + r) * lda + c];
+      const int r = e / rl, c = 2 * (e - r * rl);
+      const d2 v = *reinterpret_cast<const d2*>(A + (long)(16 * I + r) * lda + c);
+      double* dst = S + tri_base(I, c >> 4) + r * TLD + (c & 15);
+      dst[0] = v.x;
+      dst[1] = v.y;
     }
   }
   if (tid == 0) failflag = 0;
@@ -478,9 +368,14 @@ static __device__ __forceinline__ void leaf_body_tri(const double* __restrict__ 
     }
     return;
   }
-  for (int e = tid; e < 128 * 128; e += 512) {
-    const int ii = e >> 7, jj = e & 127;
-    L[(long)ii * ldl + jj] = ((jj >> 4) <= (ii >> 4)) ? S[tri_base(ii >> 4, jj >> 4) + (ii & 15) * TLD + (jj & 15)] : 0.0;
+  for (int e = tid; e < 128 * 64; e += 512) {
+    const int ii = e >> 6, jj = (e & 63) * 2;
+    d2 v = {0.0, 0.0};
+    if ((jj >> 4) <= (ii >> 4)) {
+      const double* src = S + tri_base(ii >> 4, jj >> 4) + (ii & 15) * TLD + (jj & 15);
+      v = (d2){src[0], src[1]};
+    }
+    *reinterpret_cast<d2*>(L + (long)ii * ldl + jj) = v;
   }
   __syncthreads();
   if (tid < 128) {
@@ -574,199 +469,54 @@ static __device__ __forceinline__ void leaf_body_tri(const double* __restrict__ 
     }
   }
   LEAF_STAMP(6);
-  for (int e = tid; e < 128 * 128; e += 512) {
-    const int ii = e >> 7, jj = e & 127;
-    Dinv[e] = ((jj >> 4) < (ii >> 4) || ((jj >> 4) == (ii >> 4) && jj <= ii)) ? S[tri_base(ii >> 4, jj >> 4) + (ii & 15) * TLD + (jj & 15)] : 0.0;
+  for (int e = tid; e < 128 * 64; e += 512) {
+    const int ii = e >> 6, jj = (e & 63) * 2;
+    d2 v = {0.0, 0.0};
+    if ((jj >> 4) <= (ii >> 4)) {  // (the diagonal blocks hold zeros above the diagonal: leaf_diag_block_mfma wrote them, the inverse kept them)
+      const double* src = S + tri_base(ii >> 4, jj >> 4) + (ii & 15) * TLD + (jj & 15);
+      v = (d2){src[0], (jj + 1 <= ii) ? src[1] : 0.0};
+    }
+    *reinterpret_cast<d2*>(Dinv + (long)ii * 128 + jj) = v;
   }
   LEAF_STAMP(7);
 }
 
 __global__ __launch_bounds__(512, 4) void potf2_trtri_128_slot_kernel(const double* __restrict__ A, long lda, double* __restrict__ L,
                                                                       long ldl, double* __restrict__ Dinv, int* info, int col0,
-                                                                      int dbg_skip) {
+                                                                      int dbg_skip, unsigned* guest) {
   __shared__ __attribute__((aligned(16))) double S[TRI_DOUBLES];
   __shared__ double rinvb[16];
   __shared__ int failflag;
+  // announce the guest on this CU (gpk_internal.h: the GEMM workgroups that share the CU pause while the counter is up)
+  unsigned* gslot = nullptr;
+  if (guest && threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+    gslot = guest + (((xcc & 7u) << 8) | ((hw >> 8) & 0xffu));
+    __hip_atomic_fetch_add(gslot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   leaf_body_tri(A, lda, L, ldl, Dinv, info, col0, dbg_skip, S, rinvb, failflag, (int)threadIdx.x);
+  __syncthreads();  // every path of the body ends here: the counter always comes down again
+  if (gslot) __hip_atomic_fetch_sub(gslot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int ALGO>
 __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __restrict__ A, long lda,
                                                                double* __restrict__ L, long ldl,
                                                                double* __restrict__ Dinv, int* info, int col0,
                                                                int dbg_skip) {
-  __shared__ __attribute__((aligned(16))) double S[128 * PLD + 2 * CBLD + 128];
+  __shared__ __attribute__((aligned(16))) double S[128 * PLD];
   __shared__ double rinvb[16];
   __shared__ int failflag;
-  leaf_body<ALGO>(A, lda, L, ldl, Dinv, info, col0, dbg_skip, S, rinvb, failflag, (int)threadIdx.x);
+  leaf_body(A, lda, L, ldl, Dinv, info, col0, dbg_skip, S, rinvb, failflag, (int)threadIdx.x);
 }
 
-int g_leaf_algo = 2;  // 2: slot-sized blocked leaf (512 threads, block-triangular LDS image; default); 1: the same algorithm, 1024 threads on the full tile; 0: column-by-column in registers
+// fat: the full-tile form (the caller expects an empty CU to be easy to find), else the slot-sized one
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0,
-                           int dbg_skip, hipStream_t s) {
-  if (g_leaf_algo == 2)
-    hipLaunchKernelGGL(potf2_trtri_128_slot_kernel, dim3(1), dim3(512), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
-  else if (g_leaf_algo == 0)
-    hipLaunchKernelGGL(potf2_trtri_128_kernel<0>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
+                           int dbg_skip, hipStream_t s, int fat) {
+  if (!fat)
+    hipLaunchKernelGGL(potf2_trtri_128_slot_kernel, dim3(1), dim3(512), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip, g_cu_guest);
   else
-    hipLaunchKernelGGL(potf2_trtri_128_kernel<1>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
-  GPK_HIP(hipGetLastError());
-  return 0;
-}
-
-// ---------------------------------------------------------------- resident leaf server (see gpk_internal.h)
-static __device__ __forceinline__ unsigned mb_load(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-static __device__ __forceinline__ void mb_store(unsigned* p, unsigned v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int ALGO>
-__global__ __launch_bounds__(1024) void leaf_server_kernel(LeafMailbox* mb, unsigned first_seq) {
-  __shared__ __attribute__((aligned(16))) double S[128 * PLD + 2 * CBLD + 128];
-  __shared__ double rinvb[16];
-  __shared__ int failflag;
-  __shared__ unsigned long long t_ptr[5];
-  __shared__ long t_ld[2];
-  __shared__ int t_int[3];  // col0, command (0 tile, 1 quit, 2 timed out)
-  const int tid = threadIdx.x;
-  for (unsigned seq = first_seq;; ++seq) {
-    if (tid == 0) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      int cmd = 0;
-      while (mb_load(&mb->go) != seq) {
-        __builtin_amdgcn_s_sleep(4);
-        if (mb_load(&mb->err) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > LEAF_SERVER_LIMIT_TICKS) {
-          cmd = 2;
-          break;
-        }
-      }
-      if (cmd == 0) {
-        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(mb);
-        t_ptr[0] = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // A
-        t_ld[0] = (long)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t_ptr[1] = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L
-        t_ld[1] = (long)__hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t_ptr[2] = __hip_atomic_load(q + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // Dinv
-        t_ptr[3] = __hip_atomic_load(q + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // info
-        const unsigned long long co = __hip_atomic_load(q + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t_int[0] = (int)(unsigned)(co & 0xffffffffull);
-        cmd = (int)(unsigned)(co >> 32) ? 1 : 0;
-      }
-      t_int[1] = cmd;
-    }
-    __syncthreads();
-    const int cmd = t_int[1];
-    if (cmd == 2) {
-      if (tid == 0) mb_store(&mb->err, 1u);
-      return;
-    }
-    if (cmd == 1) {
-      if (tid == 0) mb_store(&mb->done, seq);
-      return;
-    }
-    // The tile was written by an earlier kernel of the chain (complete and written back before the proxy ran) and is
-    // read past the caches; L and Dinv are written through them: no invalidate, no write-back of this XCD's L2.
-    auto uni = [](unsigned long long v) -> unsigned long long {  // workgroup-uniform: keep it in scalar registers
-      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffull));
-      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-      return ((unsigned long long)hi << 32) | lo;
-    };
-    const double* tA = reinterpret_cast<const double*>(uni(t_ptr[0]));
-    double* tL = reinterpret_cast<double*>(uni(t_ptr[1]));
-    double* tD = reinterpret_cast<double*>(uni(t_ptr[2]));
-    int* tinfo = reinterpret_cast<int*>(uni(t_ptr[3]));
-    const long tlda = (long)uni((unsigned long long)t_ld[0]), tldl = (long)uni((unsigned long long)t_ld[1]);
-    const int tcol0 = __builtin_amdgcn_readfirstlane(t_int[0]);
-    int tid_it = tid;  // a fresh value per tile: the body's index arithmetic is NOT hoisted out of the server loop
-    asm volatile("" : "+v"(tid_it));  // (hoisted, it stays live across the whole body: 11 spilled registers)
-    leaf_body<ALGO, true>(tA, tlda, tL, tldl, tD, tinfo, tcol0, 0, S, rinvb, failflag, tid_it);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left before the barrier
-    __syncthreads();
-    if (tid == 0) mb_store(&mb->done, seq);
-  }
-}
-
-__global__ __launch_bounds__(64) void leaf_proxy_kernel(LeafMailbox* mb, unsigned seq, int op, const double* A, long lda,
-                                                        double* L, long ldl, double* Dinv, int* info, int col0) {
-  if (threadIdx.x != 0) return;
-  unsigned long long* q = reinterpret_cast<unsigned long long*>(mb);
-  __hip_atomic_store(q + 0, (unsigned long long)A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(q + 1, (unsigned long long)lda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(q + 2, (unsigned long long)L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(q + 3, (unsigned long long)ldl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(q + 4, (unsigned long long)Dinv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(q + 5, (unsigned long long)info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(q + 6, (unsigned long long)(unsigned)col0 | ((unsigned long long)(unsigned)op << 32), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the task is in memory before `go` (earlier kernels' data: kernel boundary)
-  mb_store(&mb->go, seq);
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  bool ok = true;
-  while (mb_load(&mb->done) != seq) {
-    __builtin_amdgcn_s_sleep(2);
-    if (mb_load(&mb->err) != 0) { ok = false; break; }
-    if (__builtin_amdgcn_s_memrealtime() - t0 > LEAF_SERVER_LIMIT_TICKS) {
-      mb_store(&mb->err, 2u);
-      ok = false;
-      break;
-    }
-  }
-  if (!ok && info) atomicCAS(info, 0, LEAF_SERVER_INFO_POISON);
-}
-
-// The leaf of the FLAG-CHAINED tile pipeline: waits (bounded) for `wait_flag` -- set by the previous step's T kernel on the
-// update stream; nullptr for the first tile -- factors its tile with cache-bypassing accesses (the tile was written by that
-// still-running kernel through the caches), and sets `set_flag` when L and Dinv are out.
-template <int ALGO>
-__global__ __launch_bounds__(1024) void leaf_flag_kernel(const double* __restrict__ A, long lda, double* __restrict__ L, long ldl,
-                                                         double* __restrict__ Dinv, int* info, int col0, const unsigned* wait_flag,
-                                                         unsigned* set_flag) {
-  __shared__ __attribute__((aligned(16))) double S[128 * PLD + 2 * CBLD + 128];
-  __shared__ double rinvb[16];
-  __shared__ int failflag;
-  __shared__ int gave_up;
-  const int tid = threadIdx.x;
-  if (wait_flag) {
-    if (tid == 0) {
-      int bad = 0;
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (mb_load(wait_flag) == 0u) {
-        __builtin_amdgcn_s_sleep(2);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > LEAF_SERVER_LIMIT_TICKS) { bad = 1; break; }
-      }
-      gave_up = bad;
-    }
-    __syncthreads();
-    if (gave_up && tid == 0 && info) atomicCAS(info, 0, LEAF_SERVER_INFO_POISON);
-  }
-  leaf_body<ALGO, true>(A, lda, L, ldl, Dinv, info, col0, 0, S, rinvb, failflag, tid);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0 && set_flag) mb_store(set_flag, 1u);
-}
-
-int launch_leaf_flag(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, const unsigned* wait_flag,
-                     unsigned* set_flag, hipStream_t s) {
-  if (g_leaf_algo == 0) hipLaunchKernelGGL(leaf_flag_kernel<0>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, wait_flag, set_flag);
-  else hipLaunchKernelGGL(leaf_flag_kernel<1>, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, wait_flag, set_flag);
-  GPK_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_leaf_server(LeafMailbox* mb, unsigned first_seq, hipStream_t s) {
-  static_assert(offsetof(LeafMailbox, go) == 128 && offsetof(LeafMailbox, done) == 256 && offsetof(LeafMailbox, err) == 384,
-                "mailbox layout");
-  if (g_leaf_algo == 0) hipLaunchKernelGGL(leaf_server_kernel<0>, dim3(1), dim3(1024), 0, s, mb, first_seq);
-  else hipLaunchKernelGGL(leaf_server_kernel<1>, dim3(1), dim3(1024), 0, s, mb, first_seq);
-  GPK_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_leaf_proxy(LeafMailbox* mb, unsigned seq, int op, const double* A, long lda, double* L, long ldl,
-                      double* Dinv, int* info, int col0, hipStream_t s) {
-  hipLaunchKernelGGL(leaf_proxy_kernel, dim3(1), dim3(64), 0, s, mb, seq, op, A, lda, L, ldl, Dinv, info, col0);
+    hipLaunchKernelGGL(potf2_trtri_128_kernel, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, dbg_skip);
   GPK_HIP(hipGetLastError());
   return 0;
 }

@@ -27,8 +27,11 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
                         double* nlml_out, double* mean_out, double* var_out);
 
 /* ---- kernel-level test hooks (tests/ only; host buffers, row-major) --------- */
-/* C (m x n) = [C -] A (m x k) * B (n x k)^T through the MFMA kernel; tile = 128 or 64. */
-int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile);
+/* C (m x n) = [C -] A (m x k) * B (n x k)^T through the MFMA kernels; tile = 128 (8-wave LDS-DMA kernel) or 64 (the
+ * 4-wave kernel: its independent bit-for-bit cross-check).  k1 > 0: the K range split at column k1 over two separately
+ * stored operands (the paired trailing update).  xcd_order: force the XCD-aware 8x8-square tile order (tile = 128). */
+int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile, int k1,
+                     int xcd_order);
 /* the RCCL calls of the multi-rank path (broadcast on the panel stream, all-gather and all-reduce on the update
  * stream) on a one-rank communicator, payload checked: what a 1-GPU box can verify of gpk_comm.hip. */
 int gpk_test_rccl_selfcheck(int n_doubles);
@@ -52,22 +55,18 @@ int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_o
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out);
 /* LDS banking probe for rocprofv3 --pmc (scripts/lds_bank_probe.sh): `reps` ds_read_b64 per lane in one of six address patterns. */
 int gpk_bench_lds_bank_probe(int pattern, int reps);
-/* the leaf server's bounded wait: a tile posted with no server resident must come back as an error after ~5 s (0 = it did). */
-int gpk_test_leaf_server_timeout(double* seconds_out);
-/* leaf kernel timing; dbg_skip bit0 = skip elimination, bit1 = skip inverse (timing only). */
+/* leaf kernel timing; dbg_skip bit 0 = skip elimination, bit 1 = skip inverse (timing only), bit 8 = the full-tile form. */
 int gpk_bench_leaf(int dbg_skip, int reps, double* us_out);
-/* diagnostic: physical placement (xcc<<16 | se<<8 | sh<<4 | cu) of workgroups launched on the GEMM / leaf streams. */
-int gpk_debug_cu_masks(int nmain, unsigned* ids_main, int nleaf, unsigned* ids_leaf);
-/* leaf on the reserved-CU stream, alone and while the GEMM stream saturates the other CUs. */
+/* leaf on the chain stream, alone and while the update stream saturates the chip (reps bit 24: the full-tile form,
+ * bits 16..23: dbg_skip). */
 int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended);
-/* pure v_mfma_f64_16x16x4_f64 issue loop on every CU: measured fp64 MFMA peak (TFLOP/s) of this device. */
-int gpk_bench_mfma_peak(int iters, double* tflops_out);
-int gpk_bench_mfma_peak2(int nacc, int waves_per_simd, int iters, double* tflops_out);
-/* the same loop with exactly waves_per_simd (1, 2, 4, 8) waves pinned on every SIMD through the LDS allocation;
+/* v_mfma_f64_16x16x4_f64 issue loop with exactly waves_per_simd (1, 2, 4, 8) waves pinned on every SIMD through the LDS
+   allocation: the measured fp64 MFMA peak of this device;
    out[6] = TFLOP/s, shader GHz, max / min waves per occupied SIMD, SIMDs occupied, TFLOP/s by the slowest wave's cycles. */
 int gpk_bench_mfma_pinned(int waves_per_simd, int iters, double* out);
-/* factor one 128x128 SPD tile: L_out (128x128 lower) and Dinv_out = inv(L). Returns info. */
-int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out);
+/* factor one 128x128 SPD tile: L_out (128x128 lower) and Dinv_out = inv(L); full_tile: the 1024-thread form instead of
+ * the slot-sized one (bit-identical results).  Returns info. */
+int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out, int full_tile);
 
 #ifdef __cplusplus
 }

@@ -5,9 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gptest_amd import _lib
 _lib.init()
 l = _lib.lib()
-t = (ctypes.c_double * 2)()
-l.gpk_bench_mfma_peak2(8, 4, 400000, t)
-print("issue loop 4 waves/SIMD: %.2f TFLOP/s at %.3f GHz (in-kernel clock)" % (t[0], t[1]), flush=True)
+t = (ctypes.c_double * 6)()
+l.gpk_bench_mfma_pinned(4, 400000, t)
+print("issue loop, 4 waves pinned per SIMD: %.2f TFLOP/s at %.3f GHz (in-kernel clock)" % (t[0], t[1]), flush=True)
 ns = 24
 ghz = (ctypes.c_double * (ns + 1))()
 tf = ctypes.c_double()
@@ -16,4 +16,4 @@ for (m, k, nbig) in [(16128, 256, 300), (16128, 512, 160), (16128, 2048, 40), (8
     g = list(ghz)
     print("lower update m=%d K=%d x%d: %.2f TFLOP/s sustained | clock idle %.3f GHz, under load min %.3f / mean %.3f / max %.3f GHz" % (
         m, k, nbig, tf.value, g[0], min(g[1:]), sum(g[1:]) / ns, max(g[1:])), flush=True)
-_lib.shutdown(watchdog_s=10.0)
+_lib.shutdown()

@@ -4,10 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gptest_amd import _lib
 _lib.init()
 l = _lib.lib()
-t = ctypes.c_double()
+t = (ctypes.c_double * 6)()
 for it in (20000, 100000):
-    l.gpk_bench_mfma_peak(it, ctypes.byref(t))
-    print("mfma f64 16x16x4 issue-loop peak: %.2f TFLOP/s (iters=%d)" % (t.value, it))
+    l.gpk_bench_mfma_pinned(4, it, t)
+    print("mfma f64 16x16x4 issue loop, 4 waves pinned per SIMD: %.2f TFLOP/s at %.3f GHz (iters=%d)" % (t[0], t[1], it))
 ms = ctypes.c_double()
 for (m, n, k, lower, tile) in [(8192, 8192, 128, 0, 128), (8192, 8192, 256, 0, 128), (8192, 8192, 512, 0, 128), (8192, 8192, 1024, 0, 128),
                                (8192, 8192, 4096, 0, 128), (16128, 16128, 256, 1, 128), (16128, 16128, 512, 1, 128), (8192, 8192, 256, 1, 128),

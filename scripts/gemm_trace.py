@@ -1,0 +1,56 @@
+"""Where a tile's fixed cost goes: per-workgroup stamps of ONE launch of the 8-wave GEMM (library built with `make DBG=1`).
+   GPK_GEMM_DBG=32 GPK_GEMM_TRACE=/tmp/t.bin python scripts/gemm_trace.py m n k
+Prints, in microseconds: prologue (kernel entry -> first MFMA: tile decode, first two slabs by DMA, C tile), main loop, epilogue
+(stores issued), and per CU the gap between one workgroup's exit and the entry of the next one in its slot, plus how much of
+every workgroup's non-MFMA time is covered by the MFMA phase of another workgroup on the same CU."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gptest_amd import _lib
+
+m, n, k = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (7936, 8192, 512)
+path = os.environ.get("GPK_GEMM_TRACE", "/tmp/gemm_trace.bin")
+os.environ["GPK_GEMM_TRACE"] = path
+os.environ.setdefault("GPK_GEMM_DBG", "32")
+_lib.init()
+ms = ctypes.c_double()
+rc = _lib.lib().gpk_bench_gemm_nt(m, n, k, 0, 128, 3, ctypes.byref(ms))
+print("m=%d n=%d k=%d: rc=%d %.3f ms per launch, %.2f TFLOP/s" % (m, n, k, rc, ms.value, 2.0 * m * n * k / ms.value / 1e9))
+r = np.fromfile(path, dtype=np.uint64).reshape(-1, 5)
+r = r[r[:, 0] > 0]
+t0 = r[:, 0].min()
+ent, fst, lst, ext = [(r[:, i] - t0).astype(float) * 0.01 for i in range(4)]
+cu = r[:, 4].astype(int)
+print("workgroups %d on %d CUs; launch spans %.1f us" % (len(r), len(set(cu)), ext.max()))
+print("prologue (entry -> first MFMA)  mean %.2f  p50 %.2f  p90 %.2f us" % ((fst - ent).mean(), np.median(fst - ent), np.percentile(fst - ent, 90)))
+print("main loop                       mean %.2f  p50 %.2f  p90 %.2f us" % ((lst - fst).mean(), np.median(lst - fst), np.percentile(lst - fst, 90)))
+print("epilogue (stores issued)        mean %.2f  p50 %.2f us" % ((ext - lst).mean(), np.median(ext - lst)))
+gaps, cover, per_cu = [], [], []
+for c in set(cu):
+    idx = np.where(cu == c)[0]
+    idx = idx[np.argsort(ent[idx])]
+    per_cu.append(len(idx))
+    # slot turnover: every exit is matched with the first later entry on this CU
+    e_sorted = np.sort(ext[idx])
+    for x in e_sorted:
+        later = ent[idx][ent[idx] >= x]
+        if len(later):
+            gaps.append(later.min() - x)
+    # how much of each workgroup's [last MFMA, next first MFMA in the same slot] window is covered by another workgroup's main loop
+    for i in idx:
+        lo, hi = lst[i], lst[i] + 1e9
+        later = idx[ent[idx] >= ext[i]]
+        if not len(later):
+            continue
+        j = later[np.argmin(ent[later])]
+        hi = fst[j]
+        others = [o for o in idx if o != i and o != j]
+        cov = sum(max(0.0, min(hi, lst[o]) - max(lo, fst[o])) for o in others)
+        cover.append((hi - lo, min(cov, hi - lo)))
+gaps = np.array(gaps)
+print("workgroups per CU: min %d max %d" % (min(per_cu), max(per_cu)))
+print("slot turnover (exit -> next entry on the same CU): mean %.2f p50 %.2f p90 %.2f us" % (gaps.mean(), np.median(gaps), np.percentile(gaps, 90)))
+w = np.array(cover)
+print("non-MFMA window per tile (last MFMA of one tile -> first MFMA of the next in that slot): mean %.2f us, of which %.2f us (%.0f %%) lie under another workgroup's main loop on the same CU"
+      % (w[:, 0].mean(), w[:, 1].mean(), 100 * w[:, 1].sum() / w[:, 0].sum()))
+_lib.shutdown()

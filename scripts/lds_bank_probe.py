@@ -5,4 +5,4 @@ from gptest_amd import _lib
 _lib.init()
 for pat in range(6):
     _lib.check(_lib.lib().gpk_bench_lds_bank_probe(pat, 4096), "probe")
-_lib.shutdown(watchdog_s=10.0)
+_lib.shutdown()

@@ -1,6 +1,8 @@
-"""A/B of the update stream with and without its CU mask, one process per mode on one box (round 3: the slot-sized leaf).
-   python scripts/mask_ab.py            -> runs every mode as a child process and prints one table
-   python scripts/mask_ab.py child ...  -> one mode (internal)"""
+"""A/B of the leaf's two forms (slot-sized beside a loaded chip / full-tile once few rows remain: option leaf_fat_rows) and
+of the polite GEMMs, one process per mode on one box.  (Round 3 used an earlier form of this script to compare the CU-masked
+update stream of rounds 1-2 with the unmasked layout: gpurun logs quoted in DESIGN.md section 6.)
+   python scripts/leaf_form_ab.py            -> runs every mode as a child process and prints one table
+   python scripts/leaf_form_ab.py child ...  -> one mode (internal)"""
 import ctypes
 import os
 import subprocess
@@ -29,6 +31,7 @@ def child(opts):
     ua, uc = ctypes.c_double(), ctypes.c_double()
     l.gpk_bench_leaf_contended(200, ctypes.byref(ua), ctypes.byref(uc))
     print("   leaf alone %.1f us; on the chain stream %.1f us, beside back-to-back updates %.1f us" % (us.value, ua.value, uc.value), flush=True)
+    l.gpk_bench_leaf_contended((8 << 16) | 100, ctypes.byref(ua), ctypes.byref(uc))  # phase stamps of the last leaf of each run
     for (N, d, M, reps) in SIZES:
         X, y, Z, lh = synthetic_problem(N, d, M)
         ms, nl = ctypes.c_double(), ctypes.c_double()
@@ -46,23 +49,18 @@ def child(opts):
         tf = w.value / (a.value * 1e-3) / 1e12 if a.value > 0 else 0.0
         print("   N=%5d: %8.3f / %8.3f / %8.3f ms   trailing %.1f TFLOP/s (frac %.3f, %d launches)  nlml=%.12g" %
               (N, best[0], best[1], best[2], tf, tf / 78.6, int(c.value), nl.value), flush=True)
-    _lib.shutdown(watchdog_s=20.0)
+    _lib.shutdown()
 
 
-MODES = [
-    ("masked update stream, 1024-thread leaf (round 2)", {}, ["leaf_algo=1"]),
-    ("masked update stream, slot leaf", {}, ["leaf_algo=2"]),
-    ("nothing masked, slot leaf", {"GPK_RESERVE_CU": "0"}, ["leaf_server=0", "leaf_algo=2"]),
-    ("nothing masked, slot leaf, update stream at low priority", {"GPK_RESERVE_CU": "0", "GPK_MAIN_PRIO": "3"}, ["leaf_server=0", "leaf_algo=2"]),
-    ("nothing masked, 1024-thread leaf launched directly", {"GPK_RESERVE_CU": "0"}, ["leaf_server=0", "leaf_algo=1"]),
-]
+MODES = [("full-tile leaf once <= %d rows remain, polite GEMMs" % r, {}, ["leaf_fat_rows=%d" % r]) for r in (-1, 4096, 6144, 8192, 1 << 30)] + [
+    ("full-tile leaf once <= 6144 rows remain, GEMMs that never pause", {}, ["leaf_fat_rows=6144", "gemm_polite=0"])]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child(sys.argv[2:])
         sys.exit(0)
     extra = sys.argv[1:]
-    for rnd in range(2):
+    for rnd in range(1):
         for name, env, opts in MODES:
             print("[%d] %s  env=%s opts=%s" % (rnd, name, env, opts + extra), flush=True)
             e = dict(os.environ, **env)

@@ -1,6 +1,7 @@
-"""fp64 MFMA issue loop with the residency pinned (exactly W waves on every SIMD, through the LDS allocation) next to the
-dispatcher-placed loop of scripts/mfma_peak.py.  Environment: GPK_BENCH_MASKED=1 runs the pinned loop on the CU-masked update stream, GPK_BENCH_CUS=<n> sizes the grid
-for n CUs, GPK_BENCH_THREADS=512|1024 changes the workgroup size (W = 4 only).  Usage: python scripts/mfma_pinned.py"""
+"""fp64 MFMA issue loop with the residency pinned (exactly W waves on every SIMD, through the LDS allocation).
+Environment: GPK_BENCH_CUS=<n> sizes the grid for n CUs, GPK_BENCH_THREADS=512|1024 changes the workgroup size (W = 4 only).
+(The dispatcher-placed loop and the CU-masked stream it was compared with in round 2 are gone: profiles/r02_mfma_pinned_and_mask.txt.)
+Usage: python scripts/mfma_pinned.py"""
 import ctypes
 import os
 import sys
@@ -11,7 +12,6 @@ from gptest_amd import _lib
 _lib.init()
 l = _lib.lib()
 o = (ctypes.c_double * 6)()
-t = (ctypes.c_double * 2)()
 for w in (1, 2, 4, 8):
     for rep in range(2):
         rc = l.gpk_bench_mfma_pinned(w, 40000, o)
@@ -19,7 +19,4 @@ for w in (1, 2, 4, 8):
         peak = 256 * 4 * 32 * o[1] * 1e-3  # TFLOP/s at the measured shader clock
         print("pinned   W=%d: %6.2f TFLOP/s (events) %6.2f (slowest wave's cycles) at %.3f GHz = %.1f%% / %.1f%% of %.1f | waves per SIMD max %d min %d, %d SIMDs"
               % (w, o[0], o[5], o[1], 100 * o[0] / peak, 100 * o[5] / peak, peak, o[2], o[3], o[4]), flush=True)
-    if w <= 4:
-        l.gpk_bench_mfma_peak2(4, w, 40000, t)
-        print("unpinned W=%d: %6.2f TFLOP/s at %.3f GHz" % (w, t[0], t[1]), flush=True)
 _lib.shutdown()

@@ -36,4 +36,4 @@ for st in ("kbuild", "potrf", "panel", "trailing", "solve_y", "predict"):
     c = ctypes.c_double()
     l.gpk_last_timing(st.encode(), ctypes.byref(a), ctypes.byref(c))
     print("   %-9s %9.3f ms/posterior  (%d launches)" % (st, a.value / reps, int(c.value)))
-_lib.shutdown(watchdog_s=10.0)
+_lib.shutdown()

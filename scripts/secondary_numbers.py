@@ -51,4 +51,4 @@ for rep in range(2):
     t = time.perf_counter() - t0
 print("preference Laplace loop, 8192 pairs (nx = 16384), d = 4: %.1f ms, %d Newton iterations, converged %s, lml %.6f"
       % (t * 1e3, gp.last_iterations, gp.last_converged, lml), flush=True)
-_lib.shutdown(watchdog_s=10.0)
+_lib.shutdown()

@@ -31,4 +31,4 @@ dif = [1e3 * (ch[i] - ch[i - 1]) for i in range(1, len(ch))]
 print("panels %d; chain done at %.3f ms; per-panel chain step (us): %s" % (len(rows), ch[-1], " ".join("%.0f" % x for x in dif)))
 sb = [b for _, _, b in rows]
 print("substitution lag behind the chain (us): %s" % " ".join("%.0f" % (1e3 * (b - a)) for _, a, b in rows))
-_lib.shutdown(watchdog_s=10.0)
+_lib.shutdown()

@@ -28,12 +28,9 @@ def golden_cases():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("gpr_") and f.endswith(".npz"))
 
 
-# every option gpk_set_option knows, in an order that restores correctly ("nb" switches nb_auto off, so nb_auto
-# comes after it)
-OPTION_KEYS = ["nb", "nb_auto", "nb_big", "nb_big_until", "nb_small", "nb_small_from", "nb_outer", "outer_from",
-               "outer_until", "lookahead", "dist_group", "ldk_pad", "pred_gate_rows", "gemm_variant",
-               "xcd_sq", "xcd_sorted", "xcd_sq_min_tiles", "tail_rows", "tail_stream", "tt_fused", "tail_leaf_event", "tail_flags", "stamps", "pred_small_below", "small_tile_below", "leaf_algo",
-               "test_gemm_k1", "pair_update", "leaf_server", "gemm_pipe", "pipe_interleave", "fuse_predict", "solve_gemm_above", "timing"]
+# every option gpk_set_option knows (15 keys)
+OPTION_KEYS = ["nb", "nb_big_until", "nb_small_from", "nb_outer", "outer_until", "lookahead", "dist_group", "tail_rows",
+               "leaf_fat_rows", "gemm_polite", "pair_update", "fuse_predict", "small_tile_below", "stamps", "timing"]
 
 
 @pytest.fixture(autouse=True)

@@ -8,9 +8,8 @@
 #include <cmath>
 
 thread_local dim3 blockIdx, threadIdx, blockDim, gridDim;
-int g_gemm_variant = 8;
-int g_gemm_pipe = 1;
-int g_leaf_algo = 1;
+int g_gemm_polite = 1;
+unsigned* g_cu_guest = nullptr;  // the host code allocates and frees the guest table; no stand-in kernel looks at it
 
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t) {
   const int BT = tile128 ? 128 : 64;
@@ -51,52 +50,7 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t) {
   return 0;
 }
 
-// the resident leaf server on the CPU: the server launch is a no-op and a proxy does the tile itself (the host-side
-// session logic -- open, sequence numbers, quit from the destructor -- is what the sanitizer build is after)
-static unsigned g_sim_leaf_seq_expected = 0;
-int launch_leaf_server(LeafMailbox* mb, unsigned first_seq, hipStream_t) {
-  if (!mb) return gpk_set_err(-1, "sim: leaf server without a mailbox");
-  if (g_sim_leaf_seq_expected != 0) return gpk_set_err(-1, "sim: leaf server launched while another one is resident");
-  g_sim_leaf_seq_expected = first_seq;
-  return 0;
-}
-int launch_leaf_proxy(LeafMailbox* mb, unsigned seq, int op, const double* A, long lda, double* L, long ldl,
-                      double* Dinv, int* info, int col0, hipStream_t s) {
-  if (!mb || seq != g_sim_leaf_seq_expected) return gpk_set_err(-1, "sim: leaf proxy out of sequence (%u, expected %u)", seq, g_sim_leaf_seq_expected);
-  ++g_sim_leaf_seq_expected;
-  if (op == 1) {
-    g_sim_leaf_seq_expected = 0;  // the server has left
-    return 0;
-  }
-  return launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, s);
-}
-
-// flag-chained tile pipeline on the CPU: every "kernel" runs at once in host order, so a flag must already be set when its
-// waiter is "launched" -- which is exactly the enqueue-order property the device version relies on for freedom from deadlock
-int launch_leaf_flag(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, const unsigned* wait_flag,
-                     unsigned* set_flag, hipStream_t s) {
-  if (wait_flag && *wait_flag == 0) return gpk_set_err(-1, "sim: leaf enqueued before the T step it waits for");
-  int rc = launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, s);
-  if (set_flag) *set_flag = 1;
-  return rc;
-}
-int launch_tt_flag(const GemmNT& t1, const GemmNT& t2, const unsigned* leaf_flag, unsigned* ctr2, unsigned* tt_flag, int*, hipStream_t s) {
-  if (!leaf_flag || *leaf_flag == 0) return gpk_set_err(-1, "sim: T step enqueued before its leaf");
-  if (ctr2[0] || ctr2[1] || *tt_flag) return gpk_set_err(-1, "sim: T step flags not zeroed");
-  int rc = launch_gemm_nt(t1, false, s);
-  if (!rc) rc = launch_gemm_nt(t2, false, s);
-  ctr2[0] = 4; ctr2[1] = 3; *tt_flag = 1;
-  return rc;
-}
-
-int launch_tt_fused(const GemmNT& t1, const GemmNT& t2, unsigned* ctr, unsigned target, int*, hipStream_t s) {
-  if (!ctr || *ctr + 4 != target) return gpk_set_err(-1, "sim: fused T step out of sequence (counter %u, target %u)", ctr ? *ctr : 0u, target);
-  *ctr = target;
-  int rc = launch_gemm_nt(t1, false, s);
-  return rc ? rc : launch_gemm_nt(t2, false, s);
-}
-
-int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, int, hipStream_t) {
+int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, int, hipStream_t, int) {
   static thread_local double t[128][128], inv[128][128];
   for (int i = 0; i < 128; ++i)
     for (int j = 0; j < 128; ++j) t[i][j] = (j <= i) ? A[(long)i * lda + j] : 0.0;

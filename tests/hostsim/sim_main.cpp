@@ -50,19 +50,16 @@ int main() {
 
   // ---- the posterior under every panel schedule the host code knows
   check_fit_predict(make_problem(300, 3, 40), "default");
-  opt("leaf_server", 1);  // session open / sequence numbers / quit from the destructor (the stand-ins check the order)
-  check_fit_predict(make_problem(800, 3, 40), "resident leaf server");
-  opt("nb", 128); check_fit_predict(make_problem(900, 2, 33), "resident leaf server, paired updates");
-  opt("nb", 256); opt("nb_auto", 1);
-  opt("leaf_server", 0);
   check_fit_predict(make_problem(1, 1, 3), "N=1");
+  opt("leaf_fat_rows", -1); check_fit_predict(make_problem(800, 3, 40), "slot-sized leaf everywhere");
+  opt("leaf_fat_rows", 6144);
   opt("nb", 128); check_fit_predict(make_problem(900, 2, 33), "nb=128 (paired updates)");
   opt("pair_update", 0); check_fit_predict(make_problem(700, 2, 33), "nb=128 one panel per update");
   opt("pair_update", 1); opt("lookahead", 0); check_fit_predict(make_problem(500, 4, 20), "no look-ahead");
   opt("lookahead", 1); opt("fuse_predict", 0); check_fit_predict(make_problem(500, 4, 20), "unfused prediction");
-  opt("fuse_predict", 1); opt("pipe_interleave", 1); check_fit_predict(make_problem(650, 1, 20), "interleaved substitutions");
-  opt("pipe_interleave", 0); opt("nb", 256); opt("nb_auto", 1);
-  opt("nb_outer", 512); opt("outer_from", 256); opt("outer_until", 256); opt("nb_big", 256); opt("nb_big_until", 512); opt("nb_small_from", 256);
+  opt("fuse_predict", 1); opt("nb", 0);
+  // two-level blocking forced onto small problems (active from Npad >= 3 * outer_until)
+  opt("nb_outer", 1024); opt("outer_until", 256); opt("nb_big_until", 512); opt("nb_small_from", 256); opt("tail_rows", 0);
   check_fit_predict(make_problem(1300, 3, 50), "two-level blocking");
   opt("outer_until", 0); opt("nb_outer", 768); check_fit_predict(make_problem(1100, 2, 10), "two-level blocking, 768");
   opt("nb_outer", 0); opt("nb_small_from", 640); opt("tail_rows", 640); opt("nb_big_until", 512);
@@ -72,18 +69,8 @@ int main() {
   check_fit_predict(make_problem(900, 3, 20), "tile pipeline for the whole factorisation");
   CHECK(gpk_get_option("potrf_tail_from") == 0, "tile pipeline from panel 0");
   check_fit_predict(make_problem(300, 1, 5), "tile pipeline, three tiles");
-  opt("tail_rows", 0); opt("tail_stream", 0); opt("tail_rows", 1 << 30);  // the same with its full-height GEMMs on the update stream
-  check_fit_predict(make_problem(900, 3, 20), "tile pipeline on three streams");
-  CHECK(gpk_get_option("potrf_tail_from") == 0, "tile pipeline (three streams) from panel 0");
-  opt("tail_flags", 1);  // flag-chained steps: the stand-ins check that every flag is set before its waiter is enqueued
-  check_fit_predict(make_problem(1000, 3, 20), "tile pipeline, flag-chained");
-  opt("tail_flags", 0);
-  opt("tail_stream", 1);  // switching while the pipeline is on creates the stream ...
-  check_fit_predict(make_problem(700, 2, 9), "tile pipeline, stream switched on while active");
-  opt("tail_stream", 0);  // ... and drops it again
-  opt("tail_rows", 0); opt("tail_stream", 1);
-  opt("tail_rows", 0); opt("nb", 256); opt("nb_auto", 1);
-  opt("nb_outer", 2048); opt("outer_from", 24576); opt("outer_until", 8192); opt("nb_big", 512); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
+  opt("tail_rows", 0); opt("nb", 0);
+  opt("nb_outer", 2048); opt("outer_until", 8192); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
 
   // ---- block-cyclic schedule on virtual ranks (look-ahead and plain), against the one-rank factor
   for (int la : {1, 0}) for (int grp : {1, 2, 3}) {
@@ -104,6 +91,22 @@ int main() {
   opt("lookahead", 1);
   opt("dist_group", 2);
   {
+    // the automatic width schedule on block-cyclic models (512 / 256 / 128 by remaining size, thresholds scaled down):
+    // ownership blocks of 512 columns, panels of three widths inside them
+    opt("nb", 0); opt("nb_big_until", 512); opt("nb_small_from", 384); opt("tail_rows", 0);
+    const int N = 1700;
+    vec A((size_t)N * N);
+    for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) { const double v = (i == j ? N + 1.0 : 0.0) + std::cos(0.1 * (i - j)); A[(size_t)i * N + j] = A[(size_t)j * N + i] = v; }
+    vec L1((size_t)N * N), LP((size_t)N * N);
+    CHECK(gpk_test_dist_potrf(A.data(), N, 1, L1.data()) == 0, "auto widths P=1");
+    for (int P : {2, 3, 4}) {
+      CHECK(gpk_test_dist_potrf(A.data(), N, P, LP.data()) == 0, "auto widths P=%d", P);
+      CHECK(gpk_get_option("dist_lookahead_used") == 1, "look-ahead branch, auto widths P=%d", P);
+      CHECK(maxdiff(L1, LP) <= 1e-11, "auto widths P=%d diff %g", P, maxdiff(L1, LP));
+    }
+    opt("nb_big_until", 8192); opt("nb_small_from", 2048); opt("nb", 128);
+  }
+  {
     Problem p = make_problem(900, 3, 70);
     const Posterior ref = dense_posterior(p, p.N);
     for (int P : {2, 4, 8}) {
@@ -118,7 +121,7 @@ int main() {
     vec L((size_t)p.N * p.N);
     CHECK(gpk_test_dist_fit(p.X.data(), p.N, p.d, p.lh.data(), 0.0, 4, L.data()) == 0, "dist fit");
   }
-  opt("nb", 256); opt("nb_auto", 1);
+  opt("nb", 0); opt("nb_small_from", 4096); opt("tail_rows", 4096);
 
   // ---- solves, K products, gathers on one handle
   {

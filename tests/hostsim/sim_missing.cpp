@@ -12,10 +12,6 @@ HOSTSIM_ABSENT(gpk_bench_chain_step(int, int, int, double*, double*))
 HOSTSIM_ABSENT(gpk_bench_se_build(int, int, int, int, int, double*))
 HOSTSIM_ABSENT(gpk_bench_gemm_nt(int, int, int, int, int, int, double*))
 HOSTSIM_ABSENT(gpk_bench_lds_bank_probe(int, int))
-HOSTSIM_ABSENT(gpk_test_leaf_server_timeout(double*))
 HOSTSIM_ABSENT(gpk_bench_leaf(int, int, double*))
-HOSTSIM_ABSENT(gpk_debug_cu_masks(int, unsigned*, int, unsigned*))
 HOSTSIM_ABSENT(gpk_bench_leaf_contended(int, double*, double*))
-HOSTSIM_ABSENT(gpk_bench_mfma_peak(int, double*))
-HOSTSIM_ABSENT(gpk_bench_mfma_peak2(int, int, int, double*))
 HOSTSIM_ABSENT(gpk_bench_mfma_pinned(int, int, double*))

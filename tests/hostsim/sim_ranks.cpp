@@ -32,9 +32,10 @@ static int rank_main(int rank, int P, const unsigned char* uid, int out_fd) {
     CHECK(std::fabs(nl - ref.nlml) <= 1e-9 * std::fabs(ref.nlml), "%s nlml %.12g vs %.12g (rank %d of %d)", what, nl, ref.nlml, rank, P);
     CHECK(maxdiff(m, ref.mean) <= 1e-8 && maxdiff(v, ref.var) <= 1e-8, "%s mean/var %g %g (rank %d of %d)", what, maxdiff(m, ref.mean), maxdiff(v, ref.var), rank, P);
   };
-  for (int pass = 0; pass < 3; ++pass) {  // default schedule; no look-ahead; one panel / three panels per ownership block
+  for (int pass = 0; pass < 4; ++pass) {  // default schedule; no look-ahead; three panels per ownership block; panels of three widths
     if (pass == 1) opt("lookahead", 0);
     if (pass == 2) { opt("lookahead", 1); opt("dist_group", 3); }
+    if (pass == 3) { opt("dist_group", 2); opt("nb_big_until", 256); opt("nb_small_from", 256); }  // 512 / 256 / 128 / 128 at N = 900
     gpk_model* h = nullptr;
     double nl = 0;
     vec mean(p.M), var(p.M);
@@ -54,7 +55,7 @@ static int rank_main(int rank, int P, const unsigned char* uid, int out_fd) {
     }
     gpk_free(h);
   }
-  opt("dist_group", 2);
+  opt("nb_big_until", 8192); opt("nb_small_from", 4096);
   {
     gpk_model* h = nullptr;
     double nl = 0;

@@ -35,7 +35,7 @@ def test_mfma_gemm_nt(gpk, m, n, k, tile, sub, lower):
     B = A.copy() if lower else rng.randn(n, k)
     C0 = rng.randn(m, n)
     C = C0.copy()
-    rc = gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, tile)
+    rc = gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, tile, 0, 0)
     assert rc == 0, gpk.last_error()
     ref = C0 - A @ B.T if sub else A @ B.T
     if lower:
@@ -58,12 +58,9 @@ def test_mfma_gemm_nt_lower_trapezoid(gpk, m, n, k, tile):
     C0 = rng.randn(m, n)
     C = C0.copy()
     B = np.ascontiguousarray(A[:n])
-    for variant, xcd, srt in ([(8, 1, 0), (8, 2, 0), (8, 2, 1), (4, 1, 0)] if tile == 128 else [(8, 1, 0)]):
-        gpk.set_option("gemm_variant", variant)
-        gpk.set_option("xcd_sq", xcd)   # 2: force the XCD-aware 8x8-square tile order of the big updates
-        gpk.set_option("xcd_sorted", srt)  # ... with the squares enumerated full ones first, diagonal ones last
+    for xcd in ((0, 1) if tile == 128 else (0,)):  # 1: force the XCD-aware 8x8-square tile order of the big updates
         C[:] = C0
-        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, 1, tile) == 0, gpk.last_error()
+        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, 1, tile, 0, xcd) == 0, gpk.last_error()
         ref = C0 - A @ B.T
         mask = np.zeros((m, n), bool)
         for ti in range(m // tile):
@@ -74,36 +71,41 @@ def test_mfma_gemm_nt_lower_trapezoid(gpk, m, n, k, tile):
 
 @pytest.mark.parametrize("m,n,k,sub,lower", [(256, 384, 16, 1, 0), (256, 384, 32, 0, 0), (384, 256, 48, 1, 0),
                                              (1152, 1152, 80, 1, 1), (2304, 512, 256, 1, 1), (512, 640, 512, 1, 0)])
-def test_pipelined_slab_loop_is_bitwise_the_plain_loop(gpk, m, n, k, sub, lower):
-    """Option gemm_pipe (default 1): the 8-wave kernel's software-pipelined slab loop -- fragments of the next k-step
-    read under the MFMAs of the current one, the next-but-one slab written to LDS right after the barrier that releases
-    its buffer -- keeps the MFMA order over k, so C is bit for bit the plain loop's, for 1, 2, 3 and more slabs."""
+def test_lds_dma_kernel_is_bitwise_the_register_staged_kernel(gpk, m, n, k, sub, lower):
+    """The 8-wave kernel (K-slabs staged by LDS-DMA into a swizzled unpadded image, fragments prefetched across k-steps,
+    A negated by the MFMA itself, two K segments for the paired update) and the 4-wave 64x64-tile kernel (register-staged
+    plain loop, negation on the way into LDS) are independent implementations that accumulate over k in the same order:
+    C must agree bit for bit, for 1, 2, 3 and more slabs, full and lower, one and two K segments, both tile orders."""
     rng = np.random.RandomState(m + n + k)
     A = rng.randn(m, k)
     B = np.ascontiguousarray(A[:n]) if lower else rng.randn(n, k)
     C0 = rng.randn(m, n)
-    out = []
-    for pipe in (0, 1, 2):  # 2: staging by LDS-DMA (swizzled unpadded image, A negated by the MFMA itself)
-        gpk.set_option("gemm_pipe", pipe)
+
+    def run(tile, k1=0, xcd=0):
         C = C0.copy()
-        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, 128) == 0, gpk.last_error()
-        out.append(C)
-    assert np.array_equal(out[0], out[1])
-    assert np.array_equal(out[0], out[2])
-    if k >= 32:  # the two-segment form (paired trailing update), register-staged and LDS-DMA-staged
-        for pipe in (0, 2):
-            gpk.set_option("gemm_pipe", pipe)
-            gpk.set_option("test_gemm_k1", 16 if k < 256 else 128)
-            C = C0.copy()
-            assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, 128) == 0, gpk.last_error()
-            assert np.array_equal(out[0], C)
-    ref = C0 - A @ B.T if sub else A @ B.T
+        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, tile, k1, xcd) == 0, gpk.last_error()
+        return C
+
+    ref64 = run(64)
     mask = np.ones((m, n), bool)
-    if lower:
+    if lower:  # tiles above the diagonal are untouched; the two kernels differ in tile size, so compare where both computed
         mask[:] = False
         for ti in range(m // 128):
             mask[ti * 128:(ti + 1) * 128, :min(n, (ti + 1) * 128)] = True
-    np.testing.assert_allclose(out[1][mask], ref[mask], rtol=1e-12, atol=1e-12)
+        m64 = np.zeros((m, n), bool)
+        for ti in range(m // 64):
+            m64[ti * 64:(ti + 1) * 64, :min(n, (ti + 1) * 64)] = True
+        assert np.all(m64 <= mask)
+    else:
+        m64 = mask
+    c128 = run(128)
+    assert np.array_equal(c128[m64], ref64[m64])
+    assert np.array_equal(run(128, 0, 1), c128)
+    if k >= 32:  # the two-segment form (paired trailing update)
+        assert np.array_equal(run(128, 16 if k < 256 else 128), c128)
+    ref = C0 - A @ B.T if sub else A @ B.T
+    np.testing.assert_allclose(c128[mask], ref[mask], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(c128[~mask], C0[~mask])
 
 
 @pytest.mark.parametrize("sub", [0, 1])
@@ -115,7 +117,7 @@ def test_tile_sizes_round_identically(gpk, sub):
     out = []
     for tile in (64, 128):
         C = C0.copy()
-        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 256, 384, 96, sub, 0, tile) == 0
+        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 256, 384, 96, sub, 0, tile, 0, 0) == 0
         out.append(C)
     np.testing.assert_array_equal(out[0], out[1])
 
@@ -130,12 +132,8 @@ def test_two_segment_k_is_bitwise_one_update(gpk, m, n, k, k1, lower):
     C0 = rng.randn(m, n)
     out = []
     for split in (0, k1):
-        gpk.set_option("test_gemm_k1", split)
         C = C0.copy()
-        try:
-            assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, lower, 128) == 0, gpk.last_error()
-        finally:
-            gpk.set_option("test_gemm_k1", 0)
+        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, lower, 128, split, 0) == 0, gpk.last_error()
         out.append(C)
     np.testing.assert_array_equal(out[0], out[1])
 
@@ -146,7 +144,7 @@ def test_mfma_fragment_layout_identity(gpk):
     A[:16, :16] = np.eye(16)
     B = np.arange(128 * 16, dtype=float).reshape(128, 16) + 0.25
     C = np.zeros((128, 128))
-    assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 128, 128, 16, 0, 0, 128) == 0
+    assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 128, 128, 16, 0, 0, 128, 0, 0) == 0
     np.testing.assert_array_equal(C, A @ B.T)
 
 
@@ -156,32 +154,32 @@ def test_leaf_factor_and_inverse(gpk):
     A = Q @ Q.T + 128 * np.eye(128)
     L = np.zeros((128, 128))
     D = np.zeros((128, 128))
-    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D)) == 0
+    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), 0) == 0
     Lr = np.linalg.cholesky(A)
     np.testing.assert_allclose(L, Lr, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(D @ Lr, np.eye(128), atol=1e-12)
     assert np.all(np.triu(L, 1) == 0) and np.all(np.triu(D, 1) == 0)
     # first non-positive pivot is reported LAPACK-style (1-based)
     A[7, 7] = -3.0
-    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D)) == 8
+    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), 0) == 8
     A[:] = np.nan
-    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D)) == 1
+    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), 1) == 1
 
 
 def test_slot_sized_leaf_is_bitwise_the_full_tile_leaf(gpk):
-    """The default leaf (option leaf_algo = 2: 512 threads, 76.6 KiB block-triangular LDS image -- the slot one finished
-    update workgroup frees, so that no CU has to be reserved for it) performs the operations of the 1024-thread / 132 KiB
-    leaf (leaf_algo = 1) in the same order: factor and inverse agree bit for bit, and so does the failure report."""
+    """The slot-sized leaf (512 threads, 76.6 KiB block-triangular LDS image -- the slot one finished update workgroup
+    frees, so that no CU has to be reserved for it) performs the operations of the full-tile leaf (1024 threads, 132 KiB;
+    used once few rows remain, option leaf_fat_rows) in the same order: factor and inverse agree bit for bit, and so does
+    the failure report."""
     rng = np.random.RandomState(5)
     for trial in range(4):
         Q = rng.randn(128, 128 if trial < 2 else 20)
         A = Q @ Q.T + (128 if trial % 2 == 0 else 1e-3) * np.eye(128)
         A[np.triu_indices(128, 1)] = np.nan if trial == 3 else A[np.triu_indices(128, 1)]  # only the lower triangle may be read
         out = []
-        for algo in (1, 2):
-            gpk.set_option("leaf_algo", algo)
+        for full in (1, 0):
             L, D = np.zeros((128, 128)), np.zeros((128, 128))
-            assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D)) == 0, gpk.last_error()
+            assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), full) == 0, gpk.last_error()
             out.append((L, D))
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
         assert np.all(np.triu(out[1][0], 1) == 0) and np.all(np.triu(out[1][1], 1) == 0)
@@ -190,10 +188,9 @@ def test_slot_sized_leaf_is_bitwise_the_full_tile_leaf(gpk):
     for bad in (0, 15, 16, 77, 127):
         B = np.eye(128) * 2.0 + 0.01
         B[bad, bad] = -1.0
-        for algo in (1, 2):
-            gpk.set_option("leaf_algo", algo)
+        for full in (1, 0):
             L, D = np.zeros((128, 128)), np.zeros((128, 128))
-            assert gpk.lib().gpk_test_potf2_128(_ptr(B), _ptr(L), _ptr(D)) == bad + 1
+            assert gpk.lib().gpk_test_potf2_128(_ptr(B), _ptr(L), _ptr(D), full) == bad + 1
             assert np.array_equal(L, np.eye(128)) and np.array_equal(D, np.eye(128))  # identity factors keep downstream kernels finite
 
 
@@ -210,47 +207,27 @@ def test_potrf_matches_numpy(gpk, N):
     assert np.all(np.triu(Ain, 1) == 0)
 
 
-@pytest.mark.parametrize("N", [640, 1500, 4096, 6000])
-def test_resident_leaf_server_is_bitwise_the_direct_leaf(gpk, N):
-    """Option leaf_server: the panel chain's leaves go through a mailbox to ONE resident workgroup (k_potf2.hip:
-    leaf_server_kernel / leaf_proxy_kernel) instead of one kernel launch per tile.  Same tile code, so the factor is
-    bit-identical; the paired (Npad <= 8192) and the plain look-ahead schedules, a failing pivot, and two factorisations
-    in a row (the second server queues behind the first one's quit message) are all covered."""
+@pytest.mark.parametrize("N", [640, 1500, 4096, 7000])
+def test_factor_does_not_depend_on_the_form_of_the_leaf(gpk, N):
+    """Option leaf_fat_rows: which of the two forms of the leaf a tile gets (slot-sized beside a loaded chip, full-tile once
+    few rows remain) and whether the GEMM workgroups pause for it (gemm_polite) are scheduling decisions: the factor is
+    bit-identical, and so is the report of a failing pivot."""
     rng = np.random.RandomState(N)
     Q = rng.randn(N, 64)
     A = Q @ Q.T + N * np.eye(N)
-    L0 = A.copy()
-    assert gpk.lib().gpk_potrf(_ptr(L0), N) == 0, gpk.last_error()
-    gpk.set_option("leaf_server", 1)
-    for rep in range(2):
-        L1 = A.copy()
-        assert gpk.lib().gpk_potrf(_ptr(L1), N) == 0, gpk.last_error()
-        assert np.array_equal(L0, L1)
-    bad = N - 7
-    B = A.copy()
-    B[bad, bad] = -1.0
-    assert gpk.lib().gpk_potrf(_ptr(B), N) == bad + 1
-    gpk.set_option("leaf_server", 0)
-    assert gpk.lib().gpk_sync() == 0
-
-
-def test_leaf_server_waits_are_bounded(gpk):
-    """A tile posted to the mailbox with no server resident: the proxy gives up after its 5 s limit, flags the mailbox and
-    poisons *info -- an error for the caller, never a hang -- and the next factorisation through a server works."""
-    import ctypes
-
-    sec = ctypes.c_double()
-    assert gpk.lib().gpk_test_leaf_server_timeout(ctypes.byref(sec)) == 0, gpk.last_error()
-    assert 4.5 < sec.value < 8.0, sec.value
-    N = 900
-    rng = np.random.RandomState(3)
-    Q = rng.randn(N, 50)
-    A = Q @ Q.T + N * np.eye(N)
-    L0, L1 = A.copy(), A.copy()
-    assert gpk.lib().gpk_potrf(_ptr(L0), N) == 0, gpk.last_error()
-    gpk.set_option("leaf_server", 1)
-    assert gpk.lib().gpk_potrf(_ptr(L1), N) == 0, gpk.last_error()
-    assert np.array_equal(L0, L1)
+    out = []
+    for fat_rows, polite in ((6144, 1), (-1, 1), (1 << 30, 1), (2048, 0)):
+        gpk.set_option("leaf_fat_rows", fat_rows)
+        gpk.set_option("gemm_polite", polite)
+        L = A.copy()
+        assert gpk.lib().gpk_potrf(_ptr(L), N) == 0, gpk.last_error()
+        out.append(L)
+        bad = N - 7
+        B = A.copy()
+        B[bad, bad] = -1.0
+        assert gpk.lib().gpk_potrf(_ptr(B), N) == bad + 1
+    for L in out[1:]:
+        assert np.array_equal(out[0], L)
 
 
 @pytest.mark.parametrize("N,bad", [(5, 3), (300, 131), (520, 519)])
@@ -284,19 +261,14 @@ def test_potrf_block_size_invariance(gpk, nb):
     (4096, {"nb_small_from": 4096, "tail_rows": 4096}, 0),                           # BASELINE config 2's size
 ])
 def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_from):
-    """potrf_tail (leaf + one-tile kernels on the chain stream, full-height panel GEMMs on a second stream or in front of
-    the bulk on the update stream, bulk on the update stream) applies to every element the same rank-128 updates in the same order as the panel-level look-ahead
-    with the same 128-wide panels: the factors must agree bit for bit, and with NumPy's."""
+    """potrf_tail (leaf + one-tile kernels on the chain stream, full-height panel GEMMs in front of the bulk on the update
+    stream) applies to every element the same rank-128 updates in the same order as the panel-level look-ahead with the
+    same 128-wide panels: the factors must agree bit for bit, and with NumPy's."""
     rng = np.random.RandomState(N)
     Q = rng.randn(N, N)
     A = Q @ Q.T + N * np.eye(N)
     out = []
-    for tail in (0, 1, 2, 3, 4, 5):  # 5: flag-chained steps (option tail_flags); 0: panel level; 1: full-height GEMMs on a stream of their own; 2: on the update stream (option tail_stream = 0); 3: ... and the chain's two one-tile GEMMs as two launches (tt_fused = 0); 4: ... with a separate event after every leaf
-        gpk.set_option("tail_rows", 0)
-        gpk.set_option("tail_stream", 1 if tail == 1 else 0)
-        gpk.set_option("tt_fused", 1 if tail in (1, 2) else 0)
-        gpk.set_option("tail_leaf_event", 1 if tail == 4 else 0)
-        gpk.set_option("tail_flags", 1 if tail == 5 else 0)
+    for tail in (0, 1):
         for k, v in opts.items():
             gpk.set_option(k, 0 if (k == "tail_rows" and not tail) else v)
         gpk.set_option("pair_update", 0)
@@ -309,10 +281,6 @@ def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_fro
             assert tf == -1
         out.append(L)
     np.testing.assert_array_equal(out[0], out[1])
-    np.testing.assert_array_equal(out[0], out[2])
-    np.testing.assert_array_equal(out[0], out[3])
-    np.testing.assert_array_equal(out[0], out[4])
-    np.testing.assert_array_equal(out[0], out[5])
     Lr = np.linalg.cholesky(A)
     np.testing.assert_allclose(out[1], Lr, rtol=1e-11, atol=1e-11 * np.abs(Lr).max())
     # not positive definite inside the tail: same LAPACK-style report
@@ -451,7 +419,7 @@ def test_multi_rhs_solve_on_the_gemm_path(gpk, N, d, nrhs):
     B = np.ascontiguousarray(rng.randn(N, nrhs))
     K = orc.kxx(lh, X)
     c = cho_factor(K, lower=True)
-    assert nrhs > gpk.get_option("solve_gemm_above")
+    assert nrhs > 8  # more right-hand sides than that take the blocked GEMM substitutions (Runtime::solve_gemm_above)
     out = np.empty_like(B)
     t0 = time.perf_counter()
     assert gpk.lib().gpk_solve(h.ptr, _ptr(B), nrhs, _ptr(out)) == 0, gpk.last_error()
@@ -462,16 +430,18 @@ def test_multi_rhs_solve_on_the_gemm_path(gpk, N, d, nrhs):
     assert gpk.lib().gpk_solve_lower(h.ptr, _ptr(B), nrhs, _ptr(low)) == 0, gpk.last_error()
     refl = solve_triangular(c[0], B, lower=True)
     np.testing.assert_allclose(low, refl, rtol=0, atol=1e-9 * np.abs(refl).max())
-    # the one-vector-at-a-time path on the same factor
-    gpk.set_option("solve_gemm_above", 1 << 30)
+    # the one-vector-at-a-time path on the same factor: eight columns per call
     col = np.empty_like(B)
     t0 = time.perf_counter()
-    assert gpk.lib().gpk_solve(h.ptr, _ptr(B), nrhs, _ptr(col)) == 0, gpk.last_error()
+    for j0 in range(0, min(nrhs, 64), 8):
+        Bj = np.ascontiguousarray(B[:, j0:j0 + 8])
+        oj = np.empty_like(Bj)
+        assert gpk.lib().gpk_solve(h.ptr, _ptr(Bj), Bj.shape[1], _ptr(oj)) == 0, gpk.last_error()
+        col[:, j0:j0 + 8] = oj
     t_col = time.perf_counter() - t0
-    np.testing.assert_allclose(out, col, rtol=0, atol=1e-9 * np.abs(ref).max())
-    print("nrhs=%d N=%d: GEMM path %.1f ms, column loop %.1f ms" % (nrhs, N, 1e3 * t_gemm, 1e3 * t_col))
-    if nrhs >= 512:
-        assert t_col > 2.0 * t_gemm   # measured 6.4x (521 ms vs 81 ms); the bound is loose on purpose (timing on a shared box)
+    nc = min(nrhs, 64)
+    np.testing.assert_allclose(out[:, :nc], col[:, :nc], rtol=0, atol=1e-9 * np.abs(ref).max())
+    print("nrhs=%d N=%d: GEMM path %.1f ms for all, column loop %.1f ms for %d columns" % (nrhs, N, 1e3 * t_gemm, 1e3 * t_col, nc))
 
 
 def test_not_positive_definite_fit_raises(gpk):
@@ -509,7 +479,7 @@ def test_full_size_posterior_matches_fixture(gpk, name):
     from gptest_amd import GPr
 
     g, X, y, Z, lh = _full_fixture(name)
-    assert gpk.get_option("nb_auto") == 1 and gpk.get_option("lookahead") == 1 and gpk.get_option("fuse_predict") == 1
+    assert gpk.get_option("nb") == 0 and gpk.get_option("lookahead") == 1 and gpk.get_option("fuse_predict") == 1
     gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", X, y)
     fz, cov = gp.compute_prediction(Z)          # cold cache: the fused fit + predict pipeline
     nlml = gp.compute_likelihood(lh)[0, 0]
@@ -1261,22 +1231,23 @@ def test_gpy_compat_optimize_uses_the_device_gradient(gpk):
 
 # ----------------------------------------------------------------------------- retained alternative code paths
 @pytest.mark.parametrize("opts", [
-    {"leaf_algo": 0},                                    # column-by-column leaf elimination
-    {"small_tile_below": 0, "pred_small_below": 96},     # 128x128 tiles for every panel update
-    {"pipe_interleave": 1},                              # substitutions submitted right after their panel
+    {"leaf_fat_rows": -1},                               # the slot-sized leaf for every tile
+    {"leaf_fat_rows": 1 << 30, "gemm_polite": 0},        # the full-tile leaf for every tile, GEMMs that never pause
+    {"small_tile_below": 0},                             # 128x128 tiles for every panel update
     {"fuse_predict": 0},                                 # prediction after the factorisation
     {"lookahead": 0},                                    # one stream, no look-ahead
     {"nb": 128},                                         # uniform panels instead of the 512/256/128 schedule
+    {"nb": 512},
     {"pair_update": 0},                                  # one panel per trailing update
     {"pair_update": 2, "nb": 128},                       # paired updates on more than five panels
-    # two-level blocking (outer panels applied with K = nb_outer) forced onto a small problem, several shapes
-    {"nb_outer": 512, "outer_from": 256, "outer_until": 256, "nb_big": 256, "nb_big_until": 512, "nb_small_from": 256},
-    {"nb_outer": 768, "outer_from": 256, "outer_until": 128, "nb_big": 256, "nb_big_until": 0, "nb_small_from": 0},
-    {"nb_outer": 512, "outer_from": 256, "outer_until": 600, "pipe_interleave": 1},
-    {"nb_outer": 1024, "outer_from": 256, "outer_until": 0, "fuse_predict": 0},
+    # two-level blocking (outer panels applied with K = nb_outer; on from Npad >= 3 * outer_until) forced onto a small problem
+    {"nb_outer": 1024, "outer_until": 256, "nb_big_until": 512, "nb_small_from": 256},
+    {"nb_outer": 768, "outer_until": 128, "nb_big_until": 0, "nb_small_from": 0},
+    {"nb_outer": 512, "outer_until": 500},
+    {"nb_outer": 1024, "outer_until": 0, "fuse_predict": 0},
     {"nb_outer": 0},
     {"nb": 128, "tail_rows": 1 << 30},                                              # tile pipeline for everything
-    {"nb_small_from": 1024, "tail_rows": 1024, "pipe_interleave": 1},               # ... for the last 1024 columns
+    {"nb_small_from": 1024, "tail_rows": 1024},                                     # ... for the last 1024 columns
 ])
 def test_option_paths_keep_parity(gpk, opts):
     """Every switch that selects another kernel or schedule must leave the posterior within the parity bar."""
@@ -1308,8 +1279,9 @@ def test_option_paths_keep_parity(gpk, opts):
 
 
 def test_rccl_calls_on_a_one_rank_communicator(gpk):
-    """All a 1-GPU box can check of gpk_comm.hip: panel-sized ncclBroadcast on the panel stream, ncclAllGather and
-    ncclAllReduce on the CU-masked update stream, on a one-rank communicator, payload intact."""
+    """All a 1-GPU box can check of gpk_comm.hip: panel-sized ncclBroadcast on a high-priority stream (as the communication
+    stream is), ncclAllGather and ncclAllReduce on the update stream, on a one-rank communicator, payload intact.  (The
+    multi-rank branches run with 2 and 4 real processes on the CPU: tests/test_hostsim.py.)"""
     assert gpk.lib().gpk_test_rccl_selfcheck(16384 * 256) == 0, gpk.last_error()
 
 
@@ -1361,11 +1333,12 @@ def test_api_rejects_empty_and_malformed_calls(gpk):
     np.testing.assert_allclose(c32, co32, rtol=0, atol=RTOL)
 
 
-# ----------------------------------------------------------------------------- process teardown (round-1 verdict item 6)
+# ----------------------------------------------------------------------------- process teardown
 def test_shutdown_reinit_and_clean_process_exit(gpk):
-    """A child process runs the pattern that used to hang at exit (heavy use of the CU-masked update stream only, then
+    """A child process runs the pattern that used to hang at exit in rounds 1-2 (heavy use of the update stream, then
     shutdown -- explicit, and again from the interpreter-exit handler after a re-init) and must END by itself with
-    status 0: gpk_shutdown leaves the masked stream to process teardown (scripts/shutdown_probe.py has the matrix)."""
+    status 0.  gpk_shutdown destroys every stream it created (there is no CU-masked stream any more), in one fixed order,
+    from the calling thread."""
     import subprocess
     import sys
     from conftest import ROOT
@@ -1380,10 +1353,10 @@ l = _lib.lib()
 ms = ctypes.c_double()
 for lower in (1, 0, 1, 0):
     assert l.gpk_bench_se_build(4096, 8, 0, lower, 5, ctypes.byref(ms)) == 0
-_lib.shutdown()                                  # explicit: everything but the masked stream is destroyed
+_lib.shutdown()                                  # explicit: every stream, event and pooled buffer is released
 rng = np.random.RandomState(0)
 X = rng.rand(700, 2); y = rng.randn(700); lh = np.log([0.5, 0.5, 1.0, 0.1])
-h, nl = GPr.fit_handle(X, y, lh)                 # re-initialises, reusing the parked stream
+h, nl = GPr.fit_handle(X, y, lh)                 # re-initialises
 assert np.isfinite(nl)
 for lower in (1, 0):
     assert l.gpk_bench_se_build(4096, 8, 0, lower, 5, ctypes.byref(ms)) == 0
