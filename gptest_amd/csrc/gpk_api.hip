@@ -1210,6 +1210,29 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
   g.m = m; g.n = n; g.k = k; g.sub = 1; g.lower = lower & 1;
   auto go = [&]() { return tile == 64 ? launch_gemm_nt(g, false, s) : launch_gemm_auto(g, s); };
 #ifdef GPK_GEMM_DBG_VARIANTS
+  // GPK_GEMM_TRACE=<file> with GPK_GEMM_DBG=32: per-workgroup stamps of ONE launch (after a warm-up launch) as raw u64[8] records
+  extern unsigned long long* g_gemm_trace;
+  if (getenv("GPK_GEMM_TRACE") && tile != 64) {
+    const size_t nw = (size_t)8 * 65536;
+    unsigned long long* dtr = nullptr;
+    GPK_HIP(hipMalloc((void**)&dtr, nw * 8));
+    GPK_HIP(hipMemset(dtr, 0, nw * 8));
+    (void)go();
+    GPK_HIP(hipStreamSynchronize(s));
+    g_gemm_trace = dtr;
+    (void)go();
+    GPK_HIP(hipStreamSynchronize(s));
+    g_gemm_trace = nullptr;
+    std::vector<unsigned long long> h(nw);
+    GPK_HIP(hipMemcpy(h.data(), dtr, nw * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dtr);
+    if (FILE* f = fopen(getenv("GPK_GEMM_TRACE"), "wb")) {
+      fwrite(h.data(), 8, nw, f);
+      fclose(f);
+    }
+  }
+#endif
+#ifdef GPK_GEMM_DBG_VARIANTS
   // GPK_GEMM_TRACE=<file> with GPK_GEMM_DBG=32: per-workgroup stamps of ONE launch (after a warm-up launch) as raw u64[5] records
   extern unsigned long long* g_gemm_trace;
   if (getenv("GPK_GEMM_TRACE") && tile != 64) {

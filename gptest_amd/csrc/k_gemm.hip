@@ -30,7 +30,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define LDS_LD (BK + 2)
 
 unsigned* g_cu_guest = nullptr;
-unsigned long long* g_gemm_trace = nullptr;  // make DBG=1, GPK_GEMM_DBG=32: five words per workgroup (entry, first MFMA, last MFMA, exit in 10 ns ticks; CU slot)
+unsigned long long* g_gemm_trace = nullptr;  // make DBG=1, GPK_GEMM_DBG=32: eight words per workgroup (entry, first MFMA, last MFMA, exit in 10 ns ticks; CU slot; set-up done, loads issued, loads landed)
 int g_gemm_polite = 1;  // option gemm_polite: 0 = the GEMM workgroups do not look at the guest table
 // this wave's slot in the guest table
 static __device__ __forceinline__ unsigned cu_guest_slot() {
@@ -222,14 +222,14 @@ static __device__ __forceinline__ void glds16(const double* sbase, unsigned voff
 
 // TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update).  NEG = (sub != 0).
 // DBG (make DBG=1, timing only, wrong results): 1 no DMA in the loop, 2 no barriers, 8 no C load / store, 16 every tile reads
-// tile 0's first slab; 32 (right results) per-workgroup time stamps into g.trace.
+// tile 0's first slab; 32 (right results) per-workgroup time stamps into g.trace.  (A raised wave priority for the prologue and the store tail -- s_setprio 3 -- shortens the prologue by 2 us and lengthens the neighbour's slab loop by as much: profiles/r03_gemm_tile_trace.txt.)
 template <bool TWOSEG, bool NEG, int DBG = 0>
 __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   constexpr int BT = 128;
   // the unpadded LDS image, exactly 64 KiB: two workgroups per CU leave 32 KiB, and ONE finished workgroup frees a 96 KiB
   // slot, which is what the slot-sized leaf (k_potf2.hip) is built to fit
   __shared__ double lds[2 * 2 * BT * BK];
-  unsigned long long st_entry = 0, st_first = 0, st_last = 0;
+  unsigned long long st_entry = 0, st_first = 0, st_last = 0, st_a = 0, st_b = 0, st_c = 0;
   if (DBG & 32) st_entry = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -393,10 +393,13 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   // guest poll (gpk_internal.h): wave 0 only; the value read during one slab is looked at after the next barrier
   const unsigned* gslot = (wid == 0 && g.guest) ? g.guest + cu_guest_slot() : nullptr;
   unsigned gv = 0;
+  if (DBG & 32) st_a = __builtin_amdgcn_s_memrealtime();
   dma(0, 0);
   if (nk > 1) dma(1, 1);
   init_acc();  // (the first two slabs are requested BEFORE the C tile, which queues behind them in the load path)
+  if (DBG & 32) st_b = __builtin_amdgcn_s_memrealtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (DBG & 32) st_c = __builtin_amdgcn_s_memrealtime();
   __syncthreads();
   if (DBG & 32) st_first = __builtin_amdgcn_s_memrealtime();
   rd(0, 0, 0);
@@ -464,8 +467,9 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
         __hip_atomic_store((Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16) + c_off, acc[i][j][r], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
   if ((DBG & 32) && g.trace && tid == 0) {
-    unsigned long long* t = g.trace + 5 * (size_t)blockIdx.x;
+    unsigned long long* t = g.trace + 8 * (size_t)blockIdx.x;
     t[0] = st_entry; t[1] = st_first; t[2] = st_last; t[3] = __builtin_amdgcn_s_memrealtime(); t[4] = cu_guest_slot();
+    t[5] = st_a; t[6] = st_b; t[7] = st_c;
   }
 }
 

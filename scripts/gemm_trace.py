@@ -16,13 +16,15 @@ _lib.init()
 ms = ctypes.c_double()
 rc = _lib.lib().gpk_bench_gemm_nt(m, n, k, 0, 128, 3, ctypes.byref(ms))
 print("m=%d n=%d k=%d: rc=%d %.3f ms per launch, %.2f TFLOP/s" % (m, n, k, rc, ms.value, 2.0 * m * n * k / ms.value / 1e9))
-r = np.fromfile(path, dtype=np.uint64).reshape(-1, 5)
+r = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
 r = r[r[:, 0] > 0]
 t0 = r[:, 0].min()
 ent, fst, lst, ext = [(r[:, i] - t0).astype(float) * 0.01 for i in range(4)]
 cu = r[:, 4].astype(int)
 print("workgroups %d on %d CUs; launch spans %.1f us" % (len(r), len(set(cu)), ext.max()))
 print("prologue (entry -> first MFMA)  mean %.2f  p50 %.2f  p90 %.2f us" % ((fst - ent).mean(), np.median(fst - ent), np.percentile(fst - ent, 90)))
+sa, sb, sc = [(r[:, i] - t0).astype(float) * 0.01 for i in (5, 6, 7)]
+print("   of it: entry -> set-up done %.2f | DMA + C loads issued %.2f | loads landed (wave 0) %.2f | first barrier %.2f us" % ((sa - ent).mean(), (sb - sa).mean(), (sc - sb).mean(), (fst - sc).mean()))
 print("main loop                       mean %.2f  p50 %.2f  p90 %.2f us" % ((lst - fst).mean(), np.median(lst - fst), np.percentile(lst - fst, 90)))
 print("epilogue (stores issued)        mean %.2f  p50 %.2f us" % ((ext - lst).mean(), np.median(ext - lst)))
 gaps, cover, per_cu = [], [], []
