@@ -11,8 +11,9 @@ What runs where
 * K + eps*I, its Cholesky, logdetK and every Newton iteration (GPpref.py:122-155): libgpk.so
   (``gpk_fit`` with the keep-K flag, then ``gpk_pref_laplace``).  The reference forms the explicit inverse
   ``iK`` and ``inv(iK + W)`` (2 nx^3 per iteration); the GPU path never inverts K (see k_pref.hip).
-* ``PrefProbit`` keeps its NumPy methods for API compatibility (``derivatives`` still returns the dense W
-  the reference returns), but ``calc_laplace`` does not call them.
+* ``PrefProbit`` keeps the reference's methods and return values (``derivatives`` still returns the dense W), with the
+  per-pair terms computed by the same device kernel as the Laplace loop (``gpk_pref_pair_stats``); ``calc_laplace`` itself
+  never forms W.
 
 Reference quirks kept for parity: probit sigma stays at the constructor default because
 ``self.likelihood.set_sigma = ...`` (GPpref.py:115) assigns over the method; ``logdetK`` is
@@ -46,7 +47,12 @@ def std_norm_pdf(x):
 
 
 class PrefProbit(object):
-    """GPpref.py:46-94 (host NumPy; small vectors)."""
+    """The probit pair likelihood, GPpref.py:46-94: same methods, same return values (``derivatives`` still hands back
+    the dense ``W`` and the column ``dpy_df`` the reference's callers expect), but the per-pair terms -- ``Phi``, ``N``,
+    their ratio, the gradient and curvature weights, ``log Phi`` -- come from the device kernel the Laplace loop itself
+    runs (``pref_pair_stats_kernel`` through ``gpk_pref_pair_stats``); only the scatter into the caller's dense arrays is
+    NumPy.  The reference's scatter rules are kept: ``dpy_df[idx] += v`` drops repeated indices (GPpref.py:77-78) while
+    the ``W`` loop accumulates them (GPpref.py:82-87)."""
 
     def __init__(self, sigma=1.0):
         self.set_sigma(sigma)
@@ -57,40 +63,45 @@ class PrefProbit(object):
         self._isqrt2sig = 1.0 / (self.sigma * np.sqrt(2.0))
         self._i2var = self._isqrt2sig ** 2
 
+    def _pair_terms(self, uvi, y, f):
+        """(z, q, c, log Phi) per pair from the device."""
+        uv = np.ascontiguousarray(uvi, dtype=np.int64)
+        npairs = uv.shape[0]
+        fv, fp = _lib.as_c(np.reshape(f, -1))
+        yv, yp = _lib.as_c(np.broadcast_to(np.reshape(y, -1), (npairs,)))
+        out, op = _lib.out_array((4, npairs))
+        ptr = lambda k: ctypes.cast(ctypes.addressof(op.contents) + 8 * k * npairs, _lib.c_double_p)
+        _lib.init()
+        _lib.check(_lib.lib().gpk_pref_pair_stats(uv.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), yp, npairs,
+                                                  float(self.sigma), fp, len(fv), ptr(0), ptr(1), ptr(2), ptr(3)),
+                   "gpk_pref_pair_stats")
+        return out[0], out[1], out[2], out[3]
+
     def z_k(self, uvi, f, y):
         zc = self._isqrt2sig * (f[uvi[:, 1]] - f[uvi[:, 0]])
         return y * zc
 
     def I_k(self, x, uv):
-        if x == uv[0]:
-            return -1
-        elif x == uv[1]:
-            return 1
-        return 0
+        return -1 if x == uv[0] else (1 if x == uv[1] else 0)
 
     def derivatives(self, uvi, y, f):
-        """Dense (W, dpy_df) exactly as GPpref.py:68-88 returns them (vectorised scatter instead of the loop)."""
+        """(W (nx, nx), dpy_df (nx, 1)) as GPpref.py:68-88 returns them."""
         nx = len(f)
-        z = self.z_k(uvi, f, y)
-        phi_z = std_norm_cdf(z)
-        N_z = std_norm_pdf(z)
+        _, q, c, _ = self._pair_terms(uvi, y, f)
+        u, v = np.asarray(uvi)[:, 0], np.asarray(uvi)[:, 1]
         dpy_df = np.zeros((nx, 1), dtype="float")
-        dpyuv_df = y * self._isqrt2sig * N_z / phi_z
-        dpy_df[uvi[:, 0]] += -dpyuv_df
-        dpy_df[uvi[:, 1]] += dpyuv_df
-        inner = (-self._i2var * (z * N_z / phi_z + (N_z / phi_z) ** 2)).reshape(-1)
+        dpy_df[u] += -q.reshape(-1, 1)
+        dpy_df[v] += q.reshape(-1, 1)
         W = np.zeros((nx, nx), dtype="float")
-        u, v = uvi[:, 0], uvi[:, 1]
-        np.subtract.at(W, (u, u), inner)
-        np.subtract.at(W, (v, v), inner)
-        np.add.at(W, (u, v), inner)
-        np.add.at(W, (v, u), inner)
+        np.add.at(W, (u, u), c)
+        np.add.at(W, (v, v), c)
+        np.subtract.at(W, (u, v), c)
+        np.subtract.at(W, (v, u), c)
         return W, dpy_df
 
     def log_marginal(self, uvi, y, f, iK, logdetK):
-        z = self.z_k(uvi, f, y)
-        phi_z = std_norm_cdf(z)
-        psi = (np.sum(np.log(phi_z)) - 0.5 * np.matmul(np.matmul(f.T, iK), f)
+        _, _, _, logphi = self._pair_terms(uvi, y, f)
+        psi = (np.sum(logphi) - 0.5 * np.matmul(np.matmul(f.T, iK), f)
                - 0.5 * logdetK - iK.shape[0] / 2.0 * self.log2pi)
         return psi.flat[0]
 

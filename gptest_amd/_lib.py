@@ -58,6 +58,7 @@ def _bind(l):
         "gpk_model_get_L": (i, [vp, dp]),
         "gpk_free": (i, [vp]),
         "gpk_pref_laplace": (i, [vp, ctypes.POINTER(ctypes.c_longlong), dp, i, d, dp, d, i, dp, ctypes.POINTER(ctypes.c_int), dp]),
+        "gpk_pref_pair_stats": (i, [ctypes.POINTER(ctypes.c_longlong), dp, i, d, dp, i, dp, dp, dp, dp]),
         "gpk_pref_predict": (i, [vp, ctypes.POINTER(ctypes.c_longlong), dp, i, d, dp, dp, i, dp, dp]),
         "gpk_append": (i, [c_void_pp, dp, dp, i, dp]),
         "gpk_class_laplace": (i, [vp, dp, i, dp, d, i, dp, ctypes.POINTER(ctypes.c_int), dp]),

@@ -82,6 +82,10 @@ void gpk_shutdown(void) {
   G.hstamps.clear();
   if (g_cu_guest) (void)hipFree(g_cu_guest);
   g_cu_guest = nullptr;
+  graph_cache_clear();
+  for (auto& kv : G.hpin_pool)
+    for (double* q : kv.second) (void)hipHostFree(q);
+  G.hpin_pool.clear();
   timers_reset();
   for (hipEvent_t e : G.ev_free) (void)hipEventDestroy(e);
   G.ev_free.clear();
@@ -106,6 +110,8 @@ int gpk_sync(void) {
 int gpk_set_option(const char* key, double value) {
   std::string k(key ? key : "");
   const int v = (int)value;
+  G.opt_epoch++;          // a launch graph captured under other options is never replayed
+  graph_cache_clear();
   if (k == "nb") {  // 0: the automatic 512 / 256 / 128 schedule (default); otherwise uniform panels of this width
     if (v < 0 || v % 128) return gpk_set_err(-1, "option nb=%d must be 0 (automatic) or a positive multiple of 128", v);
     G.nb = v;
@@ -135,6 +141,8 @@ int gpk_set_option(const char* key, double value) {
     G.fuse_predict = v;
   } else if (k == "small_tile_below") {
     G.small_tile_below = v;
+  } else if (k == "graphs") {
+    G.graphs = v ? 1 : 0;
   } else if (k == "stamps") {
     G.stamps = v;
   } else if (k == "timing") {
@@ -160,8 +168,12 @@ double gpk_get_option(const char* key) {
   if (k == "pair_update") return G.pair_update;
   if (k == "fuse_predict") return G.fuse_predict;
   if (k == "small_tile_below") return G.small_tile_below;
+  if (k == "graphs") return G.graphs;
   if (k == "stamps") return G.stamps;
   if (k == "timing") return G.timing;
+  if (k == "graph_captures") return (double)G.graph_captures;
+  if (k == "graph_replays") return (double)G.graph_replays;
+  if (k == "graph_fallback") return G.graph_fallback.empty() ? 0.0 : 1.0;
   // read-only state
   if (k == "pool_bytes") return (double)G.pool_bytes;
   if (k == "potrf_enqueue_ms") return G.last_potrf_enqueue_ms;

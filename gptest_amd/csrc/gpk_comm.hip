@@ -67,8 +67,13 @@ int gpk_comm_init(int rank, int nranks, const void* uid128) {
   }
   G.s_pred = nullptr;
   int lo = 0, hi = 0;
-  GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  GPK_HIP(hipStreamCreateWithPriority(&G.s_comm, hipStreamNonBlocking, hi));
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (hipStreamCreateWithPriority(&G.s_comm, hipStreamNonBlocking, hi) != hipSuccess) {
+    // the communicator is up: go on without a stream of its own (the broadcasts then run on the panel chain's stream,
+    // comm_stream() in gpk_core.hip) rather than leave the process half initialised
+    (void)hipGetLastError();
+    G.s_comm = nullptr;
+  }
   return 0;
 }
 
@@ -101,8 +106,8 @@ int gpk_comm_barrier(void) {
 }
 
 // Self-check of the RCCL calls this library makes, on a ONE-rank communicator (all a 1-GPU box can host): the same
-// datatypes, counts and streams as the multi-rank path -- panel-sized ncclBroadcast on the high-priority panel
-// stream, ncclAllGather and ncclAllReduce(max) on the CU-masked update stream -- with the payload checked afterwards.
+// datatypes, counts and stream pairing as the multi-rank path -- panel-sized ncclBroadcast on a high-priority
+// communication stream, ncclAllGather and ncclAllReduce(max) on the update stream -- with the payload checked afterwards.
 // It cannot prove anything about links between GPUs; it does prove the calls are accepted on these streams.
 int gpk_test_rccl_selfcheck(int n_doubles) {
   GPK_TRY(rt_require());
@@ -115,13 +120,25 @@ int gpk_test_rccl_selfcheck(int n_doubles) {
   double *a = nullptr, *b = nullptr;
   int rc = 0;
   const size_t n = (size_t)n_doubles;
+  hipStream_t sc = nullptr;
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&sc, hipStreamNonBlocking, hi) != hipSuccess) {
+      (void)hipGetLastError();
+      ncclCommDestroy(c);
+      return gpk_set_err(-2, "gpk_test_rccl_selfcheck: no communication stream");
+    }
+  }
   if (dev_alloc_t(&a, n) || dev_alloc_t(&b, n)) rc = -2;
   std::vector<double> h(n), back(n);
   for (size_t i = 0; i < n; ++i) h[i] = (double)(i % 1000) - 499.5;
   do {
     if (rc) break;
     if (hipMemcpy(a, h.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    ncclResult_t r = ncclBroadcast(a, a, n, ncclDouble, 0, c, G.s_pred ? G.s_pred : G.s_panel);  // an unmasked high-priority stream, as the communication stream is
+    // the broadcast on a high-priority stream of its own while the all-gather / all-reduce use the update stream: the
+    // stream pairing of the production path (potrf_group broadcasts on G.s_comm, fit_group / predict_group reduce on s_main)
+    ncclResult_t r = ncclBroadcast(a, a, n, ncclDouble, 0, c, sc);
     if (r == ncclSuccess) r = ncclAllGather(a, b, n, ncclDouble, c, G.s_main);
     if (r == ncclSuccess) r = ncclAllReduce(b, b, n, ncclDouble, ncclMax, c, G.s_main);
     if (r != ncclSuccess) { rc = gpk_set_err(-3, "RCCL call failed: %s", ncclGetErrorString(r)); break; }
@@ -134,6 +151,7 @@ int gpk_test_rccl_selfcheck(int n_doubles) {
   if (b) dev_free(b, n * 8);
   (void)hipDeviceSynchronize();
   ncclCommDestroy(c);
+  (void)hipStreamDestroy(sc);
   return rc;
 }
 

@@ -210,6 +210,7 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   rc |= dev_alloc_t(&m->dL, m->L_elems);
   rc |= dev_alloc_t(&m->dDinv, (size_t)m->nT * 128 * 128);
   rc |= dev_alloc_t(&m->dscal, 8);
+  rc |= dev_alloc(reinterpret_cast<void**>(&m->dse), sizeof(SEParams));
   m->dws_bytes = (size_t)64 * std::max(nb, G.nb_big) * 8;
   rc |= dev_alloc(reinterpret_cast<void**>(&m->dws), m->dws_bytes);
   rc |= dev_alloc_t(&m->dinfo, 4);
@@ -221,20 +222,25 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   return 0;
 }
 
+// Buffers and events go back in the REVERSE order of model_create / model_events, so that the next model of the same shape
+// -- an optimiser evaluates one shape hundreds of times, GP_regression_demo.py:44 -- gets the very same pointers and event
+// handles back from the pools field by field: its launch graph is then found in the cache (fit_device) instead of captured.
 void model_destroy(gpk_model* m) {
   if (!m) return;
   const size_t np = m->Npad;
-  dev_free(m->dX, m->dX_elems * 8);
-  dev_free(m->dy, np * 8);
-  dev_free(m->dw, np * 8);
-  dev_free(m->dK, np * (size_t)m->ldk * 8);
-  if (m->dKcopy) dev_free(m->dKcopy, np * np * 8);
-  dev_free(m->dL, m->L_elems * 8);
-  dev_free(m->dDinv, (size_t)m->nT * 128 * 128 * 8);
-  dev_free(m->dscal, 64);
-  dev_free(m->dws, m->dws_bytes);
   dev_free(m->dinfo, 16);
-  for (hipEvent_t e : m->ev) G.ev_dep_free.push_back(e);
+  dev_free(m->dws, m->dws_bytes);
+  dev_free(m->dse, sizeof(SEParams));
+  dev_free(m->dscal, 64);
+  dev_free(m->dDinv, (size_t)m->nT * 128 * 128 * 8);
+  dev_free(m->dL, m->L_elems * 8);
+  if (m->dKcopy) dev_free(m->dKcopy, np * np * 8);
+  dev_free(m->dK, np * (size_t)m->ldk * 8);
+  dev_free(m->dw, np * 8);
+  dev_free(m->dy, np * 8);
+  dev_free(m->dX, m->dX_elems * 8);
+  if (m->hpin) G.hpin_pool[m->hpin_doubles].push_back(m->hpin);
+  for (size_t i = m->ev.size(); i-- > 0;) G.ev_dep_free.push_back(m->ev[i]);
   delete m;
 }
 
@@ -875,7 +881,7 @@ int build_K(gpk_model* m) {
     if (nc < 0) nc = 0;
     // column points of this block (clamped pointer: nc == 0 blocks are pure padding)
     const double* Cc = m->dX + (size_t)(nc > 0 ? cg0 : 0) * m->d;
-    GPK_TRY(launch_se_build(m->dX, m->N, np_, Cc, nc, m->OB, m->se, 1, 0, m->dK + (size_t)lb * m->OB, m->ldk, 1, s, cg0));
+    GPK_TRY(launch_se_build(m->dX, m->N, np_, Cc, nc, m->OB, m->se, 1, 0, m->dK + (size_t)lb * m->OB, m->ldk, 1, s, cg0, m->dX));
   }
   return 0;
 }
@@ -993,25 +999,19 @@ int fit_group(gpk_model* const* ms, int n) {
   return 0;
 }
 
-int fit_device(gpk_model* m, const FusedPredict* fp) {
+// Everything one fit queues on the three streams, from the K build to the read-back into the model's pinned staging
+// buffer -- no synchronisation, no allocation of device memory: the body fit_device either runs eagerly or captures into
+// a launch graph.  dse: hyper-parameters from device memory (graph mode) or nullptr (by value).
+static int fit_enqueue(gpk_model* m, const FusedPredict* fp, const SEParams* dse) {
   hipStream_t s = G.s_main;
   const int np_ = m->Npad;
-  if (m->P > 1) {
-    if (fp) return gpk_set_err(-1, "internal: fused prediction on a block-cyclic model");
-    if (m->virtual_rank) return gpk_set_err(-1, "internal: virtual ranks are fitted as a group (fit_group)");
-    gpk_model* one = m;
-    return fit_group(&one, 1);
-  }
+  const double* sf2_dev = dse ? &dse->sf2 : nullptr;
   timer_begin("kbuild", s, (m->keep_k ? 8.0 : 4.0) * np_ * np_ + 8.0 * m->N * m->d);
-  GPK_TRY(build_K(m));
+  GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s, 0, nullptr, dse));
   timer_end("kbuild", s);
   if (m->keep_k)
     GPK_HIP(hipMemcpy2DAsync(m->dKcopy, (size_t)np_ * 8, m->dK, (size_t)m->ldk * 8, (size_t)np_ * 8, np_, hipMemcpyDeviceToDevice, s));
-  if (m->k_only) {
-    if (!m->keep_k) return gpk_set_err(-1, "internal: a K-only model must keep K");
-    GPK_HIP(hipStreamSynchronize(s));
-    return 0;
-  }
+  if (m->k_only) return 0;
   timer_begin("potrf", s);
   hipEvent_t ev_kb = nullptr;
   const bool fuse = fp && G.fuse_predict && G.s_pred && m->P == 1 && G.lookahead && m->nP >= 3;
@@ -1053,12 +1053,8 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     if (m->has_y) GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, sy));
     if (fuse) {
       timer_begin("predict", sq);
-      GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq));
+      GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq, 0, nullptr, dse));
     }
-  }
-  if (G.stamps && !G.dstamps && m->nP <= 512) {
-    GPK_HIP(hipMalloc((void**)&G.dstamps, 1024 * 8));
-    G.hstamps.assign(1024, 0);
   }
   if (G.stamps && G.dstamps) GPK_HIP(hipMemsetAsync(G.dstamps, 0, 1024 * 8, s));
   const auto host_t0 = std::chrono::steady_clock::now();
@@ -1096,24 +1092,152 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   }
   if (fp) {
     if (fused_done) {
-      GPK_TRY(launch_row_stats(fp->dV, np_, fp->M, np_, m->dw, m->se.sf2, fp->dmean, fp->dvar, s));
+      GPK_TRY(launch_row_stats(fp->dV, np_, fp->M, np_, m->dw, m->se.sf2, fp->dmean, fp->dvar, s, sf2_dev));
     } else {
       GPK_TRY(predict_device(m, fp->dZ, fp->M, fp->Mpad, fp->dR, fp->dV, fp->dmean, fp->dvar));
     }
   }
-  double hs[2] = {0, 0};
-  int hinfo = 0;
-  GPK_HIP(hipMemcpyAsync(hs, m->dscal, 16, hipMemcpyDeviceToHost, s));
-  GPK_HIP(hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s));
-  if (fp && fp->h_mean) GPK_HIP(hipMemcpyAsync(fp->h_mean, fp->dmean, (size_t)fp->M * 8, hipMemcpyDeviceToHost, s));
-  if (fp && fp->h_var) GPK_HIP(hipMemcpyAsync(fp->h_var, fp->dvar, (size_t)fp->M * 8, hipMemcpyDeviceToHost, s));
+  // read-back into the model's pinned staging buffer: one synchronisation (the caller's) for scalars, info, mean, variance
+  GPK_HIP(hipMemcpyAsync(m->hpin, m->dscal, 16, hipMemcpyDeviceToHost, s));
+  GPK_HIP(hipMemcpyAsync(m->hpin + 2, m->dinfo, 4, hipMemcpyDeviceToHost, s));
+  if (fp) {
+    GPK_HIP(hipMemcpyAsync(m->hpin + 4, fp->dmean, (size_t)fp->M * 8, hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipMemcpyAsync(m->hpin + 4 + fp->M, fp->dvar, (size_t)fp->M * 8, hipMemcpyDeviceToHost, s));
+  }
   if (G.stamps && G.dstamps) GPK_HIP(hipMemcpyAsync(G.hstamps.data(), G.dstamps, 1024 * 8, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+void graph_cache_clear() {
+#ifndef GPK_HOSTSIM
+  for (auto& e : G.graph_cache)
+    if (e.exec) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
+#endif
+  G.graph_cache.clear();
+}
+
+int fit_device(gpk_model* m, const FusedPredict* fp) {
+  hipStream_t s = G.s_main;
+  if (m->P > 1) {
+    if (fp) return gpk_set_err(-1, "internal: fused prediction on a block-cyclic model");
+    if (m->virtual_rank) return gpk_set_err(-1, "internal: virtual ranks are fitted as a group (fit_group)");
+    gpk_model* one = m;
+    return fit_group(&one, 1);
+  }
+  if (m->k_only && !m->keep_k) return gpk_set_err(-1, "internal: a K-only model must keep K");
+  // everything the enqueue may allocate is allocated up front (a captured enqueue must not touch the allocator)
+  const size_t need = 4 + (fp ? 2 * (size_t)fp->M : 0);
+  if (m->hpin_doubles < need) {
+    if (m->hpin) G.hpin_pool[m->hpin_doubles].push_back(m->hpin);
+    m->hpin = nullptr;
+    auto it = G.hpin_pool.find(need);
+    if (it != G.hpin_pool.end() && !it->second.empty()) {
+      m->hpin = it->second.back();
+      it->second.pop_back();
+    } else {
+      GPK_HIP(hipHostMalloc((void**)&m->hpin, need * 8));
+    }
+    m->hpin_doubles = need;
+  }
+  if (G.stamps && !G.dstamps && m->nP <= 512) {
+    GPK_HIP(hipMalloc((void**)&G.dstamps, 1024 * 8));
+    G.hstamps.assign(1024, 0);
+  }
+  GPK_TRY(model_events(m, 7 * m->nP + 8));
+  m->hpin[2] = 0.0;
+  int rc = 0;
+  bool done = false;
+#ifndef GPK_HOSTSIM
+  // ---- launch graph: capture the enqueue once per (shape, buffers, schedule), replay it afterwards.  Only the
+  // hyper-parameters change between replays, and those are read from device memory (m->dse, rewritten below).
+  G.graph_fallback.clear();
+  const bool want_graph = G.graphs && !G.timing && !G.stamps && !m->keep_k && !m->k_only && !m->growable && G.lookahead && m->nP >= 3 && G.s_pred;
+  if (want_graph) {
+    std::vector<unsigned long long> key = {G.opt_epoch, (unsigned long long)m->N, (unsigned long long)m->d, (unsigned long long)m->Npad,
+                                           (unsigned long long)m->has_y, (unsigned long long)(uintptr_t)m->dX, (unsigned long long)(uintptr_t)m->dy,
+                                           (unsigned long long)(uintptr_t)m->dw, (unsigned long long)(uintptr_t)m->dK, (unsigned long long)(uintptr_t)m->dL,
+                                           (unsigned long long)(uintptr_t)m->dDinv, (unsigned long long)(uintptr_t)m->dscal, (unsigned long long)(uintptr_t)m->dws,
+                                           (unsigned long long)(uintptr_t)m->dinfo, (unsigned long long)(uintptr_t)m->dse, (unsigned long long)(uintptr_t)m->hpin,
+                                           (unsigned long long)(uintptr_t)g_cu_guest};
+    if (fp)
+      for (unsigned long long v : {(unsigned long long)fp->M, (unsigned long long)(uintptr_t)fp->dZ, (unsigned long long)(uintptr_t)fp->dR,
+                                   (unsigned long long)(uintptr_t)fp->dV, (unsigned long long)(uintptr_t)fp->dmean, (unsigned long long)(uintptr_t)fp->dvar})
+        key.push_back(v);
+    for (hipEvent_t e : m->ev) key.push_back((unsigned long long)(uintptr_t)e);  // (the captured waits name these events)
+    GPK_HIP(hipMemcpyAsync(m->dse, &m->se, sizeof(SEParams), hipMemcpyHostToDevice, s));
+    Runtime::GraphEntry* hit = nullptr;
+    for (auto& e : G.graph_cache)
+      if (e.key == key) hit = &e;
+    if (!hit) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+      if (ce == hipSuccess) {
+        const int erc = fit_enqueue(m, fp, m->dse);
+        ce = hipStreamEndCapture(s, &graph);
+        if (erc != 0) {
+          G.graph_fallback = std::string("enqueue failed during capture: ") + gpk_err_cstr();
+          ce = hipErrorUnknown;
+        } else if (ce != hipSuccess || !graph) {
+          G.graph_fallback = std::string("hipStreamEndCapture: ") + hipGetErrorString(ce);
+          if (ce == hipSuccess) ce = hipErrorUnknown;
+        }
+        if (ce == hipSuccess) {
+          // (with or without hipGraphInstantiateFlagUseNodePriority: the same times, profiles/r03_launch_graph.txt)
+          ce = hipGraphInstantiateWithFlags(&exec, graph, hipGraphInstantiateFlagUseNodePriority);
+          if (ce != hipSuccess) G.graph_fallback = std::string("hipGraphInstantiate: ") + hipGetErrorString(ce);
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+      } else {
+        G.graph_fallback = std::string("hipStreamBeginCapture: ") + hipGetErrorString(ce);
+      }
+      if (ce == hipSuccess && exec) {
+        if (G.graph_cache.size() >= 8) {  // least recently used out
+          size_t lru = 0;
+          for (size_t i = 1; i < G.graph_cache.size(); ++i)
+            if (G.graph_cache[i].last_use < G.graph_cache[lru].last_use) lru = i;
+          (void)hipGraphExecDestroy((hipGraphExec_t)G.graph_cache[lru].exec);
+          G.graph_cache.erase(G.graph_cache.begin() + lru);
+        }
+        G.graph_cache.push_back({key, (void*)exec, 0});
+        hit = &G.graph_cache.back();
+        G.graph_captures++;
+      } else {
+        (void)hipGetLastError();
+        // never silently: say once per process why this shape runs eagerly
+        static bool said = false;
+        if (!said) fprintf(stderr, "libgpk: launch-graph capture failed (%s); fits run eagerly\n", G.graph_fallback.c_str());
+        said = true;
+      }
+    }
+    if (hit) {
+      hit->last_use = ++G.graph_clock;
+      const auto host_t0 = std::chrono::steady_clock::now();
+      GPK_HIP(hipGraphLaunch((hipGraphExec_t)hit->exec, s));
+      G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+      G.last_pipe_enqueue_ms = 0.0;
+      G.graph_replays++;
+      g_potrf_lookahead_used = 1;
+      done = true;
+    }
+  }
+#endif
+  if (!done) rc = fit_enqueue(m, fp, nullptr);
+  if (rc) {
+    (void)hipStreamSynchronize(s);
+    return rc;
+  }
   GPK_HIP(hipStreamSynchronize(s));
+  if (m->k_only) return 0;
+  int hinfo = 0;
+  std::memcpy(&hinfo, m->hpin + 2, 4);
+  if (fp && fp->h_mean) std::memcpy(fp->h_mean, m->hpin + 4, (size_t)fp->M * 8);
+  if (fp && fp->h_var) std::memcpy(fp->h_var, m->hpin + 4 + fp->M, (size_t)fp->M * 8);
   m->info = hinfo;
   if (hinfo > 0) return hinfo > m->N ? m->N : hinfo;
   m->factored = true;
-  m->logdet = hs[0];
-  m->quad = m->has_y ? hs[1] : 0.0;
+  m->logdet = m->hpin[0];
+  m->quad = m->has_y ? m->hpin[1] : 0.0;
   // GPr.py:64-69: err_y + det_Kxx + occams_razor
   m->nlml = m->has_y ? 0.5 * m->quad + m->logdet + 0.5 * m->N * std::log(2.0 * M_PI) : m->logdet;
   return 0;

@@ -53,7 +53,7 @@ extern "C" int gpk_append(gpk_model** handle_inout, const double* X_new, const d
     const int rows = np_ - t0;  // tile rows to (re)compute, a multiple of 128
     // K[t0:, t0:] (lower tiles; identity on the padding) straight into the trailing block of dK
     GPK_TRY(launch_se_build(m->dX + (size_t)t0 * d, n_new - t0, rows, m->dX + (size_t)t0 * d, n_new - t0, rows, m->se, 1, 0,
-                            m->dK + (size_t)t0 * m->ldk + t0, m->ldk, 1, s));
+                            m->dK + (size_t)t0 * m->ldk + t0, m->ldk, 1, s, 0, m->dX));
     if (p0 > 0) {
       Scratch sc;
       double *dR = nullptr, *dV = nullptr;

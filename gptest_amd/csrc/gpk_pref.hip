@@ -6,6 +6,37 @@
 #include "gpk_core.h"
 #include <cmath>
 
+// PrefProbit's per-pair quantities (GPpref.py:56-58, 68-80, 90-92) for host callers of the likelihood object itself:
+// z_p = y_p (f_v - f_u) / (sqrt2 sigma), q_p = y_p N(z_p) / (sqrt2 sigma Phi(z_p)) (what derivatives() scatters into dpy_df
+// with -/+ signs), c_p = (z_p N/Phi + (N/Phi)^2) / (2 sigma^2) (minus the `inner` of GPpref.py:80: W's four entries per pair
+// are +c, +c, -c, -c) and log Phi(z_p).  The same kernel the Laplace loop runs every Newton iteration.  No model handle.
+extern "C" int gpk_pref_pair_stats(const long long* uvi, const double* y, int npairs, double sigma, const double* f, int nx,
+                                   double* z_out, double* q_out, double* c_out, double* logphi_out) {
+  GPK_TRY(rt_require());
+  if (!uvi || !y || !f) return gpk_set_err(-1, "gpk_pref_pair_stats: null pointer");
+  if (npairs < 1 || nx < 1 || !(sigma > 0.0)) return gpk_set_err(-1, "gpk_pref_pair_stats: bad arguments");
+  for (int i = 0; i < 2 * npairs; ++i)
+    if (uvi[i] < 0 || uvi[i] >= nx) return gpk_set_err(-1, "gpk_pref_pair_stats: pair index %lld outside 0..%d", uvi[i], nx - 1);
+  hipStream_t s = G.s_main;
+  Scratch sc;
+  long long* duvi = nullptr;
+  double *dy = nullptr, *df = nullptr, *dout = nullptr;
+  GPK_TRY(sc.get(&duvi, (size_t)2 * npairs));
+  GPK_TRY(sc.get(&dy, (size_t)npairs));
+  GPK_TRY(sc.get(&df, (size_t)nx));
+  GPK_TRY(sc.get(&dout, (size_t)4 * npairs));
+  GPK_HIP(hipMemcpyAsync(duvi, uvi, (size_t)2 * npairs * 8, hipMemcpyHostToDevice, s));
+  GPK_HIP(hipMemcpyAsync(dy, y, (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+  GPK_HIP(hipMemcpyAsync(df, f, (size_t)nx * 8, hipMemcpyHostToDevice, s));
+  GPK_TRY(launch_pref_pair_stats(duvi, dy, df, npairs, 1.0 / (sigma * std::sqrt(2.0)), dout, dout + npairs, dout + 2 * (size_t)npairs,
+                                 dout + 3 * (size_t)npairs, s));
+  double* outs[4] = {z_out, q_out, c_out, logphi_out};
+  for (int k = 0; k < 4; ++k)
+    if (outs[k]) GPK_HIP(hipMemcpyAsync(outs[k], dout + (size_t)k * npairs, (size_t)npairs * 8, hipMemcpyDeviceToHost, s));
+  GPK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 extern "C" int gpk_pref_laplace(gpk_model* m, const long long* uvi, const double* y, int npairs, double sigma,
                                 double* f_inout, double delta_f, int max_iter, double* lml_out, int* iters_out,
                                 double* ferr_trace) {

@@ -9,21 +9,22 @@
 // points in registers, and every wave instruction stores one full 1 KiB row
 // segment (64 lanes x 16 B), so the stores are perfectly coalesced.  The
 // reference's A^2+B^2-2AB form needs four N^2 temporaries; here the distance is
-// accumulated directly as sum((a-b)^2) in registers (agrees to ~1e-16 absolute).
+// accumulated in registers: as sum((a-b)^2) in general, and for d <= 8 in the reference's own dot-product form on points
+// CENTRED on one of them (differences are unchanged, and the cancellation error eps * |x/ell|^2 of that form is then
+// governed by the spread of the data, not by its offset from the origin).
 #include "gpk_internal.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-// 2^t for t <= ~10 (the SE kernel: t = log2(sf2) - r^2 log2(e)/2), ~1 ulp: round to the nearest integer, degree-13
-// Taylor polynomial of 2^f on |f| <= 1/2 (truncation 4e-18 relative), exponent added with v_ldexp (gradual underflow
+// 2^t for t <= ~10 (the SE kernel: t = log2(sf2) - r^2 log2(e)/2), ~1 ulp: round to the nearest integer, degree-12
+// Taylor polynomial of 2^f on |f| <= 1/2 (truncation 1.7e-16 relative), exponent added with v_ldexp (gradual underflow
 // to 0 for very negative t comes for free).  ~18 VALU operations against ~30 of the library exp() with its range and
 // special-value handling: with d = 8 the builder is VALU-bound on exactly that difference.
 __device__ __forceinline__ double exp2_neg(double t) {
   t = (t < -1100.0) ? -1100.0 : t;  // not fmax: a NaN input must stay NaN (non-finite points have to fail the factorisation)
   const double n = rint(t);
   const double f = t - n;
-  double p = 1.3691488853904124e-12;   // ln2^13/13!
-  p = fma(p, f, 2.5678435993488196e-11);
+  double p = 2.5678435993488196e-11;   // ln2^12/12!  (degree 12: truncation 1.7e-16 relative on |f| <= 1/2)
   p = fma(p, f, 4.44553827187081e-10);
   p = fma(p, f, 7.054911620801121e-09);
   p = fma(p, f, 1.0178086009239696e-07);
@@ -44,13 +45,18 @@ __device__ __forceinline__ double exp2_neg(double t) {
 // base-2 exponent, and log2(sf2) is folded into it: one add + exp2_neg per element instead of two multiplies + exp().
 template <int D, int MODE>  // D = 0: runtime dimension (column points re-read from LDS)
 __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict__ R, int nr,
-                                                       const double* __restrict__ Cc, int nc, SEParams p,
+                                                       const double* __restrict__ Cc, int nc, SEParams pv,
+                                                       const SEParams* __restrict__ pd,
                                                        int same_set, int lower_only,
-                                                       double* __restrict__ out, long ld, int col_g0) {
+                                                       double* __restrict__ out, long ld, int col_g0,
+                                                       const double* __restrict__ centre) {
   constexpr int DMAX = (D == 0) ? 32 : D;
   __shared__ double rs[128 * DMAX];
   __shared__ double cs[(D == 0) ? 128 * DMAX : 1];
   __shared__ double rn[128];  // squared norms of the (scaled) row points (mode 0, D != 0)
+  // hyper-parameters by value, or from device memory (pd): a captured launch graph is replayed with new
+  // hyper-parameters by rewriting that buffer, the launch itself stays what it was (gpk_core.hip: fit_device)
+  const SEParams& p = pd ? *pd : pv;
   const int d = (D == 0) ? p.d : D;
   int tc = blockIdx.x, tr = blockIdx.y;
   if (lower_only == 2) {  // 1-D grid over the lower triangle of tiles (no workgroups that only exit)
@@ -67,11 +73,15 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const double pre = (MODE == 0) ? 0.8493218002880191 : 1.0;  // sqrt(log2(e) / 2)
   const double lsf = (MODE == 0) ? log2(p.sf2) : 0.0;
+  constexpr bool DOTFORM = (MODE == 0 && D != 0);
+  double cen[DMAX];  // dot-product form: both point sets are centred on one point (exact for the differences)
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k) cen[k] = (DOTFORM && k < d) ? centre[k] : 0.0;
 
   for (int e = tid; e < 128 * d; e += 256) {
     const int i = e / d, k = e - i * d;
     const int gi = r0 + i;
-    rs[e] = (gi < nr) ? R[(long)gi * d + k] / p.ell[k] * pre : 0.0;
+    rs[e] = (gi < nr) ? (R[(long)gi * d + k] - (DOTFORM ? centre[k] : 0.0)) / p.ell[k] * pre : 0.0;
     if (D == 0) {
       const int gc = c0 + i;
       cs[e] = (gc < nc) ? Cc[(long)gc * d + k] / p.ell[k] * pre : 0.0;
@@ -82,13 +92,12 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
   // Mode 0 with register-resident column points: the exponent as |a|^2 + |b|^2 - 2 a.b (the very form of the
   // reference's squared_distance, GPr.py:4-13), 10 operations per element instead of 16; the norms are accumulated
   // in the same order as the dot product, so the diagonal is exactly 0.  Absolute error of the exponent ~1e-15.
-  constexpr bool DOTFORM = (MODE == 0 && D != 0);
   double na = 0.0, nb = 0.0;
   if (D != 0) {
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      za[k] = (ca < nc) ? Cc[(long)ca * D + k] / p.ell[k] * pre : 0.0;
-      zb[k] = (cb < nc) ? Cc[(long)cb * D + k] / p.ell[k] * pre : 0.0;
+      za[k] = (ca < nc) ? (Cc[(long)ca * D + k] - cen[k]) / p.ell[k] * pre : 0.0;
+      zb[k] = (cb < nc) ? (Cc[(long)cb * D + k] - cen[k]) / p.ell[k] * pre : 0.0;
       na = fma(za[k], za[k], na);
       nb = fma(zb[k], zb[k], nb);
     }
@@ -158,16 +167,18 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
       if (!(rok && cb < nc)) v1 = (same_set && gi == col_g0 + cb) ? 1.0 : 0.0;
     }
     d2 o = {v0, v1};
-    *reinterpret_cast<d2*>(out + (long)gi * ld + ca) = o;
+    // streamed once, read back much later: non-temporal (SE build at N = 16384, d = 8: 0.26 -> 0.24 ms, profiles/r03_kbuild_bench.txt)
+    __builtin_nontemporal_store(o, reinterpret_cast<d2*>(out + (long)gi * ld + ca));
   }
 }
 
 template <int MODE>
 static void se_build_dispatch(int dd, dim3 grid, dim3 block, hipStream_t s, const double* R, int nr, const double* Cc, int nc,
-                              const SEParams& p, int same_set, int lo, double* out, long ld, int col_g0) {
+                              const SEParams& p, const SEParams* pd, int same_set, int lo, double* out, long ld, int col_g0,
+                              const double* centre) {
 #define GPK_SE_CASE(DD)                                                                                                 \
   case DD:                                                                                                              \
-    hipLaunchKernelGGL((se_build_kernel<DD, MODE>), grid, block, 0, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0); \
+    hipLaunchKernelGGL((se_build_kernel<DD, MODE>), grid, block, 0, s, R, nr, Cc, nc, p, pd, same_set, lo, out, ld, col_g0, centre); \
     break;
   switch (dd) {
     GPK_SE_CASE(1)
@@ -179,13 +190,15 @@ static void se_build_dispatch(int dd, dim3 grid, dim3 block, hipStream_t s, cons
     GPK_SE_CASE(7)
     GPK_SE_CASE(8)
     default:
-      hipLaunchKernelGGL((se_build_kernel<0, MODE>), grid, block, 0, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0);
+      hipLaunchKernelGGL((se_build_kernel<0, MODE>), grid, block, 0, s, R, nr, Cc, nc, p, pd, same_set, lo, out, ld, col_g0, centre);
   }
 #undef GPK_SE_CASE
 }
 
 int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p,
-                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0) {
+                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0, const double* centre,
+                    const SEParams* dparams) {
+  if (!centre) centre = Cc;  // the call's first column point
   if (nr_pad % 128 || nc_pad % 128 || (ld & 1) || ((uintptr_t)out & 15))
     return gpk_set_err(-1, "se_build: padded shape %dx%d ld %ld must be tile aligned", nr_pad, nc_pad, ld);
   if (p.d < 1 || p.d > 32) return gpk_set_err(-1, "se_build: input dimension d=%d outside 1..32", p.d);
@@ -196,9 +209,9 @@ int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int n
     grid = dim3(nt * (nt + 1) / 2, 1);
     lo = 2;
   }
-  if (mode == 0) se_build_dispatch<0>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0);
-  else if (mode == 1) se_build_dispatch<1>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0);
-  else se_build_dispatch<2>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0);
+  if (mode == 0) se_build_dispatch<0>(p.d, grid, block, s, R, nr, Cc, nc, p, dparams, same_set, lo, out, ld, col_g0, centre);
+  else if (mode == 1) se_build_dispatch<1>(p.d, grid, block, s, R, nr, Cc, nc, p, dparams, same_set, lo, out, ld, col_g0, centre);
+  else se_build_dispatch<2>(p.d, grid, block, s, R, nr, Cc, nc, p, dparams, same_set, lo, out, ld, col_g0, centre);
   GPK_HIP(hipGetLastError());
   return 0;
 }

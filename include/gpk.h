@@ -116,6 +116,11 @@ int gpk_free(gpk_model* h);
 int gpk_pref_laplace(gpk_model* h, const long long* uvi, const double* y, int npairs, double sigma,
                      double* f_inout, double delta_f, int max_iter, double* lml_out, int* iters_out,
                      double* ferr_trace);
+/* PrefProbit's per-pair terms (GPpref.py:56-58, 68-80, 90-92) for callers of the likelihood object itself: z_p, the
+ * gradient weight q_p (dpy_df gets -q_p at u_p and +q_p at v_p), the curvature c_p (W gets +c_p at (u,u), (v,v) and -c_p at
+ * (u,v), (v,u): c = -inner of GPpref.py:80) and log Phi(z_p), each (npairs) or NULL.  f: (nx).  No model handle needed. */
+int gpk_pref_pair_stats(const long long* uvi, const double* y, int npairs, double sigma, const double* f, int nx,
+                        double* z_out, double* q_out, double* c_out, double* logphi_out);
 /* Latent posterior at M test inputs Z (M, d) under the Laplace approximation at f_hat (the mode gpk_pref_laplace
  * returned): mean = k*^T (K+eps I)^-1 f_hat, var = k** - k*^T (K + eps I + W^-1)^-1 k*.  The reference stops at
  * the mode (GPpref.py:157) and never predicts; SURVEY 8(f) item 2 names this as the next step.  Same handle and
