@@ -141,6 +141,9 @@ int gpk_set_option(const char* key, double value) {
     G.fuse_predict = v;
   } else if (k == "small_tile_below") {
     G.small_tile_below = v;
+  } else if (k == "pred_defer_from") {
+    if (v < -1 || (v > 0 && v % 128)) return gpk_set_err(-1, "option pred_defer_from=%d must be -1 (automatic), 0 (off) or a positive multiple of 128", v);
+    G.pred_defer_from = v;
   } else if (k == "graphs") {
     G.graphs = v ? 1 : 0;
   } else if (k == "stamps") {
@@ -168,6 +171,7 @@ double gpk_get_option(const char* key) {
   if (k == "pair_update") return G.pair_update;
   if (k == "fuse_predict") return G.fuse_predict;
   if (k == "small_tile_below") return G.small_tile_below;
+  if (k == "pred_defer_from") return G.pred_defer_from;
   if (k == "graphs") return G.graphs;
   if (k == "stamps") return G.stamps;
   if (k == "timing") return G.timing;

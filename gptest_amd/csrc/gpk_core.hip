@@ -1,5 +1,6 @@
 // Runtime + blocked Cholesky driver + fused fit/predict (host side of libgpk.so).
 #include "gpk_core.h"
+#include <memory>
 #include <cmath>
 #include <chrono>
 
@@ -942,7 +943,9 @@ int potrf_forward(gpk_model* m, double* v) {
 static int predict_diag(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s);
 static int predict_update(gpk_model* m, int p, int Mpad, int cg0, int ncols, double* dR, double* dV, hipStream_t s);
 static int predict_outer_update(gpk_model* m, int o, int Mpad, int cg0, int ncols, double* dR, double* dV, hipStream_t s);
-static int predict_step(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s);
+struct PredDefer;
+static std::shared_ptr<PredDefer> predict_defer_make(const gpk_model* m);
+static int predict_step(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s, const PredDefer* df);
 
 // Block-cyclic fit of the rank models living in this process (see potrf_group): every rank builds its block columns
 // of K, the group factors, every rank then holds all of L and runs the y substitution redundantly.
@@ -1030,6 +1033,7 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp, const SEParams* dse
   bool fused_done = false;
   hipStream_t sq = G.s_pred;
   hipStream_t sy = sq;  // one stream for both substitutions (see gpk_init on the stream count)
+  std::shared_ptr<PredDefer> defer = fuse ? predict_defer_make(m) : nullptr;
   std::function<int(int)> hook = [&](int p) -> int {
     hipEvent_t* ev_panel = m->ev.data();
     const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
@@ -1041,7 +1045,7 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp, const SEParams* dse
     }
     if (fuse) {
       if (!m->has_y || sy != sq) GPK_HIP(hipStreamWaitEvent(sq, ev_panel[p], 0));
-      GPK_TRY(predict_step(m, p, fp->Mpad, fp->dR, fp->dV, sq));
+      GPK_TRY(predict_step(m, p, fp->Mpad, fp->dR, fp->dV, sq, defer.get()));
     }
     if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + 512 + p, sq));
     return 0;
@@ -1302,13 +1306,43 @@ static int predict_outer_update(gpk_model* m, int o, int Mpad, int cg0, int ncol
 // Everything inner panel p contributes to the row substitution, in the two-level order: its diagonal solve, its
 // update of the remaining columns of ITS OUTER block column (K = inner width) and, when p closes the outer panel,
 // the outer panel's update of all columns to the right (K = outer width).
-static int predict_step(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s) {
+// Deferred far updates (option pred_defer_from): with b the first outer-panel boundary at or after the chosen column, an outer
+// panel that ends at or before b updates right away only the columns below b; the columns from b on get the updates of ALL
+// those panels, in panel order, when the substitution reaches b -- the same updates of every element in the same order, hence
+// the same bits, only later: in the factorisation's chain-bound last third, where CUs idle, instead of beside the bulk updates
+// that bound the first two (N = 16384: the first 15 panel steps take 22.3 instead of 23.7 ms, the posterior 33.1 instead of
+// 33.9; several boundaries instead of one were measured and lose: the later ones run into the end of the factorisation).
+struct PredDefer {
+  int b = 0;  // the boundary column
+};
+static int predict_defer_col(const gpk_model* m) {
+  int want = G.pred_defer_from;
+  if (want < 0) want = (m->Npad >= 12288) ? (int)((long)m->Npad * 5 / 8) : 0;  // automatic: where the N = 16384 schedule turns chain-bound
+  if (want <= 0) return 0;
+  for (int o = 1; o < m->nO; ++o)
+    if (m->oc0[o] >= want) return m->oc0[o];
+  return 0;
+}
+static int predict_step(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s, const PredDefer* df = nullptr) {
   const int o = m->pouter[p];
   const int cend = m->oc0[o] + m->ow[o], c1 = m->pc0[p] + m->pw[p];
+  if (df && p == m->ofirst[o] && m->oc0[o] == df->b)
+    for (int q = 0; q < o; ++q) GPK_TRY(predict_outer_update(m, q, Mpad, df->b, m->Npad - df->b, dR, dV, s));
   GPK_TRY(predict_diag(m, p, Mpad, dR, dV, s));
   GPK_TRY(predict_update(m, p, Mpad, c1, cend - c1, dR, dV, s));
-  if (p == m->oend[o] - 1) GPK_TRY(predict_outer_update(m, o, Mpad, cend, m->Npad - cend, dR, dV, s));
+  if (p == m->oend[o] - 1) {
+    const int upto = (df && cend <= df->b) ? df->b : m->Npad;
+    GPK_TRY(predict_outer_update(m, o, Mpad, cend, upto - cend, dR, dV, s));
+  }
   return 0;
+}
+
+static std::shared_ptr<PredDefer> predict_defer_make(const gpk_model* m) {
+  const int b = predict_defer_col(m);
+  if (b <= 0) return nullptr;
+  auto d = std::make_shared<PredDefer>();
+  d->b = b;
+  return d;
 }
 
 // V = R L^-T for Mpad rows (multiple of 128) of width Npad, R destroyed; s_main carries the result.
@@ -1316,7 +1350,7 @@ int rows_forward_solve(gpk_model* m, int Mpad, double* dR, double* dV) {
   hipStream_t sm = G.s_main, sp = G.s_panel;
   const int np_ = m->Npad, nP = m->nP, nO = m->nO;
   if (!G.lookahead || nP < 3) {
-    for (int p = 0; p < nP; ++p) GPK_TRY(predict_step(m, p, Mpad, dR, dV, sm));
+    for (int p = 0; p < nP; ++p) GPK_TRY(predict_step(m, p, Mpad, dR, dV, sm, nullptr));
     return 0;
   }
   // one outer panel of look-ahead, as in the factorisation: the latency-bound diagonal solves (and inner updates)

@@ -221,8 +221,9 @@ static __device__ __forceinline__ void glds16(const double* sbase, unsigned voff
 }
 
 // TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update).  NEG = (sub != 0).
-// DBG (make DBG=1, timing only, wrong results): 1 no DMA in the loop, 2 no barriers, 8 no C load / store, 16 every tile reads
-// tile 0's first slab; 32 (right results) per-workgroup time stamps into g.trace.  (A raised wave priority for the prologue and the store tail -- s_setprio 3 -- shortens the prologue by 2 us and lengthens the neighbour's slab loop by as much: profiles/r03_gemm_tile_trace.txt.)
+// DBG (make DBG=1, timing only, wrong results): 1 no DMA in the loop, 2 no barriers, 4 no C load, 128 no C store, 8 neither, 16 every
+// tile reads tile 0's first slab, 64 every workgroup uses one of 8 C tiles, 256 first-round workgroups start spread over a tile time;
+// 32 (right results) per-workgroup time stamps into g.trace, +512 shader cycles of the main loop in place of the set-up stamp.  (A raised wave priority for the prologue and the store tail -- s_setprio 3 -- shortens the prologue by 2 us and lengthens the neighbour's slab loop by as much: profiles/r03_gemm_tile_trace.txt.)
 template <bool TWOSEG, bool NEG, int DBG = 0>
 __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   constexpr int BT = 128;
@@ -296,12 +297,13 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   const double* Ag = (DBG & 16) ? g.A : g.A + (long)ti * BT * g.lda;  // DBG 16: every tile reads tile 0's first slab (cache hits)
   const double* Bg = (DBG & 16) ? g.B : g.B + brow0 * g.ldb;
   const int fr = lane & 15, fg = lane >> 4;
-  double* Cw = g.C + ((long)ti * BT + wm * 64) * g.ldc + (long)tj * BT + wn * 32;  // wave-uniform
+  double* Cw = (DBG & 64) ? g.C + ((long)(blockIdx.x & 7) * BT + wm * 64) * g.ldc + wn * 32  // DBG 64: every workgroup uses one of 8 C tiles (cache hits)
+                          : g.C + ((long)ti * BT + wm * 64) * g.ldc + (long)tj * BT + wn * 32;  // wave-uniform
   const unsigned c_off = (unsigned)fg * (unsigned)g.ldc + (unsigned)fr;
 
   d4 acc[4][2];
   auto init_acc = [&]() {
-    if (g.sub && !(DBG & 8)) {
+    if (g.sub && !(DBG & 8) && !(DBG & 4)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -393,6 +395,11 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   // guest poll (gpk_internal.h): wave 0 only; the value read during one slab is looked at after the next barrier
   const unsigned* gslot = (wid == 0 && g.guest) ? g.guest + cu_guest_slot() : nullptr;
   unsigned gv = 0;
+  if ((DBG & 256) && blockIdx.x < 512) {  // DBG 256: first-round workgroups start spread over one tile time (is the C hand-over a chip-wide convoy?)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long dl = (unsigned long long)(((blockIdx.x * 2654435761u) >> 29) & 7u) * (unsigned long long)g.k * 3ull;  // x/8 of 0.234 us * k, in 10 ns ticks
+    while (__builtin_amdgcn_s_memrealtime() - t0 < dl) __builtin_amdgcn_s_sleep(8);
+  }
   if (DBG & 32) st_a = __builtin_amdgcn_s_memrealtime();
   dma(0, 0);
   if (nk > 1) dma(1, 1);
@@ -402,6 +409,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   if (DBG & 32) st_c = __builtin_amdgcn_s_memrealtime();
   __syncthreads();
   if (DBG & 32) st_first = __builtin_amdgcn_s_memrealtime();
+  unsigned long long cyc0 = 0;
+  if (DBG & 512) cyc0 = __builtin_amdgcn_s_memtime();
   rd(0, 0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
@@ -444,7 +453,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     }
   }
   if (DBG & 32) st_last = __builtin_amdgcn_s_memrealtime();
-  if (DBG & 8) {
+  if (DBG & 512) st_a = __builtin_amdgcn_s_memtime() - cyc0;  // shader cycles of the main loop instead of the set-up stamp
+  if (DBG & (8 | 128)) {
     double t = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -453,6 +463,11 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) t += acc[i][j][r];
     if (t == 12345.678) Cw[c_off] = t;
+    if ((DBG & 32) && g.trace && tid == 0) {
+      unsigned long long* tr = g.trace + 8 * (size_t)blockIdx.x;
+      tr[0] = st_entry; tr[1] = st_first; tr[2] = st_last; tr[3] = __builtin_amdgcn_s_memrealtime(); tr[4] = cu_guest_slot();
+      tr[5] = st_a; tr[6] = st_b; tr[7] = st_c;
+    }
     return;
   }
   // Write-through (sc1) stores: the C tiles are not re-read before the next panel step, and lines left dirty in
@@ -529,7 +544,13 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
       case 8: GPK_DBG_LAUNCH(8); break;
       case 9: GPK_DBG_LAUNCH(9); break;
       case 16: GPK_DBG_LAUNCH(16); break;
+      case 64: GPK_DBG_LAUNCH(64); break;
+      case 256: GPK_DBG_LAUNCH(256); break;
+      case 4: GPK_DBG_LAUNCH(4); break;
+      case 128: GPK_DBG_LAUNCH(128); break;
       case 32: { GemmNT gt = g; gt.trace = g_gemm_trace; hipLaunchKernelGGL((gemm_nt8_kernel<false, true, 32>), grid, block, dyn, s, gt); } break;
+      case 544: { GemmNT gt = g; gt.trace = g_gemm_trace; hipLaunchKernelGGL((gemm_nt8_kernel<false, true, 544>), grid, block, dyn, s, gt); } break;
+      case 552: { GemmNT gt = g; gt.trace = g_gemm_trace; hipLaunchKernelGGL((gemm_nt8_kernel<false, true, 552>), grid, block, dyn, s, gt); } break;
       default: GPK_DBG_LAUNCH(0); break;
     }
 #undef GPK_DBG_LAUNCH

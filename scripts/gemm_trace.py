@@ -55,4 +55,36 @@ print("slot turnover (exit -> next entry on the same CU): mean %.2f p50 %.2f p90
 w = np.array(cover)
 print("non-MFMA window per tile (last MFMA of one tile -> first MFMA of the next in that slot): mean %.2f us, of which %.2f us (%.0f %%) lie under another workgroup's main loop on the same CU"
       % (w[:, 0].mean(), w[:, 1].mean(), 100 * w[:, 1].sum() / w[:, 0].sum()))
+
+# does a workgroup speed up while its CU-mate is out of its main loop?  D = main-loop duration, solo = the part of it during
+# which no other workgroup of the CU is between ITS first and last MFMA.  If a lone workgroup ran at the pair's rate, every
+# solo microsecond would shorten D by half a microsecond: slope of D on solo = -0.5 (and -1/3 ... for 3 per CU).
+D, S = [], []
+for c in set(cu):
+    idx = np.where(cu == c)[0]
+    for i in idx:
+        others = [o for o in idx if o != i]
+        ev = sorted([(max(fst[i], fst[o]), min(lst[i], lst[o])) for o in others if min(lst[i], lst[o]) > max(fst[i], fst[o])])
+        covered, cur = 0.0, fst[i]
+        for a, b in ev:
+            a = max(a, cur)
+            if b > a:
+                covered += b - a
+                cur = b
+        D.append(lst[i] - fst[i])
+        S.append((lst[i] - fst[i]) - covered)
+D, S = np.array(D), np.array(S)
+A = np.vstack([np.ones_like(S), S]).T
+coef = np.linalg.lstsq(A, D, rcond=None)[0]
+print("main loop D against its solo part S: D = %.2f %+.3f * S us (mean S %.2f, corr %.2f)" % (coef[0], coef[1], S.mean(), np.corrcoef(D, S)[0, 1]))
+for lo_, hi_ in ((0, 2), (2, 6), (6, 12), (12, 25), (25, 1e9)):
+    sel = (S >= lo_) & (S < hi_)
+    if sel.sum():
+        print("   solo %4.0f..%-4.0f us: %5d workgroups, main loop mean %.2f us" % (lo_, min(hi_, 999), sel.sum(), D[sel].mean()))
+if int(os.environ.get("GPK_GEMM_DBG", "32")) & 512:
+    cyc = r[:, 5].astype(float)
+    ghz = cyc / ((lst - fst) * 1e3)
+    print("shader clock over the main loops (s_memtime / s_memrealtime): mean %.3f GHz, p10 %.3f, p90 %.3f" % (ghz.mean(), np.percentile(ghz, 10), np.percentile(ghz, 90)))
+if os.environ.get("GPK_TRACE_SAVE"):
+    np.save(os.environ["GPK_TRACE_SAVE"], r)
 _lib.shutdown()

@@ -30,6 +30,8 @@ var = np.zeros(M)
 rc = l.gpk_bench_posterior(X.ctypes.data_as(P), y.ctypes.data_as(P), N, d, lh.ctypes.data_as(P), Z.ctypes.data_as(P), M, 1, reps,
                            ctypes.byref(ms), ctypes.byref(nl), mean.ctypes.data_as(P), var.ctypes.data_as(P))
 print("N=%d d=%d M=%d rc=%d  %.3f ms/posterior  (%.2f posteriors/s) nlml=%.12g" % (N, d, M, rc, ms.value / reps, 1e3 * reps / ms.value, nl.value))
+import hashlib
+print("   digest of mean | var: %s" % hashlib.sha1(mean.tobytes() + var.tobytes()).hexdigest()[:16])
 print("   host time to queue the last factorisation: %.2f ms, the pipelined substitutions: %.2f ms" % (_lib.get_option("potrf_enqueue_ms"), _lib.get_option("pipe_enqueue_ms")))
 for st in ("kbuild", "potrf", "panel", "trailing", "solve_y", "predict"):
     a = ctypes.c_double()

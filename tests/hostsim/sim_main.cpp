@@ -58,8 +58,14 @@ int main() {
   opt("pair_update", 1); opt("lookahead", 0); check_fit_predict(make_problem(500, 4, 20), "no look-ahead");
   opt("lookahead", 1); opt("fuse_predict", 0); check_fit_predict(make_problem(500, 4, 20), "unfused prediction");
   opt("fuse_predict", 1); opt("nb", 0);
+  // far-column updates of the pipelined prediction deferred to a boundary (default schedule, two boundaries; and two-level below)
+  opt("pred_defer_from", 512); check_fit_predict(make_problem(1500, 3, 40), "deferred far updates from column 512");
+  opt("pred_defer_from", 1152); check_fit_predict(make_problem(1500, 3, 40), "deferred far updates from column 1152 (the next panel start is taken)");
   // two-level blocking forced onto small problems (active from Npad >= 3 * outer_until)
   opt("nb_outer", 1024); opt("outer_until", 256); opt("nb_big_until", 512); opt("nb_small_from", 256); opt("tail_rows", 0);
+  opt("pred_defer_from", 1024);
+  check_fit_predict(make_problem(1300, 3, 50), "two-level blocking, far updates deferred to an outer boundary");
+  opt("pred_defer_from", 0);
   check_fit_predict(make_problem(1300, 3, 50), "two-level blocking");
   opt("outer_until", 0); opt("nb_outer", 768); check_fit_predict(make_problem(1100, 2, 10), "two-level blocking, 768");
   opt("nb_outer", 0); opt("nb_small_from", 640); opt("tail_rows", 640); opt("nb_big_until", 512);

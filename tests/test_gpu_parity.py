@@ -289,6 +289,42 @@ def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_fro
     assert gpk.lib().gpk_potrf(_ptr(B), N) == N - 69
 
 
+@pytest.mark.parametrize("N,d,M,opts,cols", [
+    (3000, 3, 200, {}, (512, 1024, 2048, 2944)),                                              # 512 / 256 / 128 schedule of a small model
+    (2500, 4, 130, {"nb": 128, "tail_rows": 1 << 30}, (128, 1280)),                            # the substitution behind the tile pipeline
+    (4000, 2, 300, {"nb_outer": 1024, "outer_until": 256, "nb_big_until": 512, "nb_small_from": 256}, (1024, 2048, 3072)),  # two-level: boundaries at outer panels
+])
+def test_deferred_far_updates_of_the_prediction_are_bitwise_the_immediate_ones(gpk, N, d, M, opts, cols):
+    """Option pred_defer_from: in the pipelined prediction the early panels update the columns from a boundary on only when
+    the substitution reaches it (all at once, in panel order) instead of right away -- the bulk-bound first part of the
+    factorisation is relieved of that work.  Every element receives the same updates in the same order: mean and variance must
+    be the very bits of the immediate form, whatever the boundary (also one that is no panel start: the next start is taken;
+    also one beyond the last panel: nothing is deferred)."""
+    from oracle import gpr_oracle as orc
+    l = gpk.lib()
+    X, y, Z, lh = orc.synthetic_problem(N, d, M, seed=N)
+    hc = np.ascontiguousarray(lh)
+    for k, v in opts.items():
+        gpk.set_option(k, v)
+
+    def posterior():
+        ms, nl = ctypes.c_double(), ctypes.c_double()
+        mean, var = np.zeros(M), np.zeros(M)
+        rc = l.gpk_bench_posterior(_ptr(X), _ptr(y), N, d, _ptr(hc), _ptr(Z), M, 0, 1, ctypes.byref(ms), ctypes.byref(nl), _ptr(mean), _ptr(var))
+        assert rc == 0, gpk.last_error()
+        return nl.value, mean, var
+
+    gpk.set_option("pred_defer_from", 0)
+    n0, m0, v0 = posterior()
+    for c in cols + (1 << 20,):
+        gpk.set_option("pred_defer_from", c)
+        n1, m1, v1 = posterior()
+        assert n1 == n0 and np.array_equal(m1, m0) and np.array_equal(v1, v0), c
+    nl_o, fz_o, cov_o = orc.posterior_efficient(lh, X, y, Z)
+    np.testing.assert_allclose(m0, fz_o, rtol=RTOL, atol=RTOL * np.abs(fz_o).max())
+    np.testing.assert_allclose(v0, cov_o, rtol=RTOL, atol=RTOL * np.abs(cov_o).max())
+
+
 def test_launch_graph_replay_is_bitwise_the_eager_run(gpk):
     """Option graphs (off by default: measured slower on this runtime): the multi-stream enqueue of a fit (+ fused prediction) is captured once per (shape,
     buffers, schedule) and replayed; hyper-parameters reach the replayed launches through device memory.  Replays must
@@ -1331,6 +1367,7 @@ def test_gpy_compat_optimize_uses_the_device_gradient(gpk):
     {"leaf_fat_rows": 1 << 30, "gemm_polite": 0},        # the full-tile leaf for every tile, GEMMs that never pause
     {"small_tile_below": 0},                             # 128x128 tiles for every panel update
     {"fuse_predict": 0},                                 # prediction after the factorisation
+    {"pred_defer_from": 768},                            # far-column updates of the pipelined prediction deferred to column 768
     {"lookahead": 0},                                    # one stream, no look-ahead
     {"nb": 128},                                         # uniform panels instead of the 512/256/128 schedule
     {"nb": 512},
