@@ -46,6 +46,7 @@ int gpk_init(int device) {
   GPK_HIP(hipStreamCreateWithPriority(&G.s_main, hipStreamNonBlocking, (lo + hi) / 2));
   GPK_HIP(hipStreamCreateWithPriority(&G.s_panel, hipStreamNonBlocking, hi));
   GPK_HIP(hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, hi));
+  g_chain_stream = G.s_panel;
   // guest table of the polite co-residency scheme (gpk_internal.h): one counter per physical CU
   if (!g_cu_guest) {
     GPK_HIP(hipMalloc((void**)&g_cu_guest, GPK_GUEST_SLOTS * sizeof(unsigned)));

@@ -41,6 +41,7 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 #define GPK_GUEST_SLOTS 2048
 constexpr unsigned long long GPK_GUEST_LIMIT_TICKS = 30000ull;  // 300 us
 extern unsigned* g_cu_guest;  // nullptr: nothing polls, nothing announces (k_gemm.hip)
+extern hipStream_t g_chain_stream;  // the panel-chain stream (gpk_init): 64x64-tile GEMMs queued on it run at raised wave priority
 
 struct GemmNT {
   const double* A; long lda;
@@ -61,6 +62,7 @@ struct GemmNT {
   const double* B2; long ldb2;
   int k1;
   const unsigned* guest;  // the guest table (filled in by launch_gemm_nt; nullptr = do not poll)
+  int prio;  // 64x64-tile kernel: raise the waves' issue priority (s_setprio): set by launch_gemm_nt for launches on the panel-chain stream
   unsigned long long* trace;  // timing builds only (make DBG=1): per-workgroup time stamps
 };
 // tile128 = true: the 8-wave 128x128-tile kernel (LDS-DMA staged); false: the 64x64-tile kernel (4 waves, 2x2 MFMA tiles each).

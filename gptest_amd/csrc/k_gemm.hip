@@ -30,6 +30,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define LDS_LD (BK + 2)
 
 unsigned* g_cu_guest = nullptr;
+hipStream_t g_chain_stream = nullptr;
 unsigned long long* g_gemm_trace = nullptr;  // make DBG=1, GPK_GEMM_DBG=32: eight words per workgroup (entry, first MFMA, last MFMA, exit in 10 ns ticks; CU slot; set-up done, loads issued, loads landed)
 int g_gemm_polite = 1;  // option gemm_polite: 0 = the GEMM workgroups do not look at the guest table
 // this wave's slot in the guest table
@@ -44,8 +45,12 @@ template <int WT>  // MFMA tiles per wave per dimension: 2 -> 64x64 block
 static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int bid, double* lds) {
   constexpr int BT = 2 * WT * 16;       // block tile edge
   constexpr int PASSES = BT / 32;       // 32 rows of 16 doubles per pass with 256 threads
-  double* As = lds;                     // [2][BT][LDS_LD]
-  double* Bs = lds + 2 * BT * LDS_LD;   // [2][BT][LDS_LD]
+  constexpr int LD = LDS_LD;
+  double* As = lds;                     // [2][BT][LD]
+  double* Bs = lds + 2 * BT * LD;       // [2][BT][LD]
+  // launches on the panel-chain stream: their few waves share SIMDs with the bulk update's, and every microsecond of theirs is on
+  // the critical path -- issue priority over the co-resident waves (N = 8192: -2 %, N = 4096: -1.5 %, profiles/r03_chain_prio.txt)
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -108,8 +113,8 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       d2 na = {sgn * ra[p].x, sgn * ra[p].y};
-      *reinterpret_cast<d2*>(As + (buf * BT + p * 32 + lrow) * LDS_LD + lchk) = na;
-      *reinterpret_cast<d2*>(Bs + (buf * BT + p * 32 + lrow) * LDS_LD + lchk) = rb[p];
+      *reinterpret_cast<d2*>(As + (buf * BT + p * 32 + lrow) * LD + lchk) = na;
+      *reinterpret_cast<d2*>(Bs + (buf * BT + p * 32 + lrow) * LD + lchk) = rb[p];
     }
   };
 
@@ -138,24 +143,24 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
     if (kt + 1 < nk) gload(kt + 1);
     unsigned gv = 0;
     if (gslot) gv = __hip_atomic_load(gslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double* Ab = As + (buf * BT + wm * WT * 16 + fr) * LDS_LD + fg;
-    const double* Bb = Bs + (buf * BT + wn * WT * 16 + fr) * LDS_LD + fg;
+    const double* Ab = As + (buf * BT + wm * WT * 16 + fr) * LD + fg;
+    const double* Bb = Bs + (buf * BT + wn * WT * 16 + fr) * LD + fg;
     {
       // one wave per SIMD and workgroup: the fragments of k-step s+1 are read under the MFMAs of k-step s (same MFMA
       // order, same bits), so that one LDS latency per slab is exposed instead of four
       double a[2][WT], b[2][WT];
 #pragma unroll
-      for (int i = 0; i < WT; ++i) a[0][i] = Ab[i * 16 * LDS_LD];
+      for (int i = 0; i < WT; ++i) a[0][i] = Ab[i * 16 * LD];
 #pragma unroll
-      for (int j = 0; j < WT; ++j) b[0][j] = Bb[j * 16 * LDS_LD];
+      for (int j = 0; j < WT; ++j) b[0][j] = Bb[j * 16 * LD];
 #pragma unroll
       for (int q = 0; q < BK / 4; ++q) {
         __builtin_amdgcn_sched_barrier(0);
         if (q + 1 < BK / 4) {
 #pragma unroll
-          for (int i = 0; i < WT; ++i) a[(q + 1) & 1][i] = Ab[i * 16 * LDS_LD + 4 * (q + 1)];
+          for (int i = 0; i < WT; ++i) a[(q + 1) & 1][i] = Ab[i * 16 * LD + 4 * (q + 1)];
 #pragma unroll
-          for (int j = 0; j < WT; ++j) b[(q + 1) & 1][j] = Bb[j * 16 * LDS_LD + 4 * (q + 1)];
+          for (int j = 0; j < WT; ++j) b[(q + 1) & 1][j] = Bb[j * 16 * LD + 4 * (q + 1)];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -516,7 +521,9 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
     nblk = (long)ntm * ntn;
   }
   if (!tile128) {
-    hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, g);
+    GemmNT h = g;
+    h.prio = (s == g_chain_stream) ? 1 : 0;
+    hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, h);
     GPK_HIP(hipGetLastError());
     return 0;
   }

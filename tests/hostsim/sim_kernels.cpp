@@ -10,6 +10,7 @@
 thread_local dim3 blockIdx, threadIdx, blockDim, gridDim;
 int g_gemm_polite = 1;
 unsigned* g_cu_guest = nullptr;  // the host code allocates and frees the guest table; no stand-in kernel looks at it
+hipStream_t g_chain_stream = nullptr;  // set by gpk_init; only the device kernel reads what follows from it
 
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t) {
   const int BT = tile128 ? 128 : 64;
