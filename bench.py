@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--dim", dest="d", type=int, default=8)
     ap.add_argument("--test-m", dest="m", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip roofline.sustained (its 24 extra update launches would be counted by the kernel-trace / PMC scripts)")
     ap.add_argument("--opt", action="append", default=[], help="libgpk option key=value (experiments; defaults are the product)")
     args = ap.parse_args()
 
@@ -243,7 +245,7 @@ def main():
         # the clock drops from the ~2.36 GHz of the memory-free issue loop above to ~2.0-2.2 GHz: the ceiling of a sustained update
         # is 256 CUs x 4 SIMDs x 32 flop x THAT clock, not the nominal 78.6 TFLOP/s `frac` is quoted against.
         sustained = None
-        if world == 1 and peak_measured is not None:
+        if world == 1 and peak_measured is not None and not args.no_clock_probe:
             try:
                 ns = 8
                 ghz = (ctypes.c_double * (ns + 1))()

@@ -1074,7 +1074,9 @@ __global__ void clock_probe_kernel(unsigned long long* out, int spin) {
 }
 int gpk_bench_clock_under_load(int m, int k, int nbig, int nsamp, double* ghz_out, double* tflops_out) {
   GPK_TRY(rt_require());
-  hipStream_t sm = G.s_main, sp = G.s_panel;
+  // the load runs on the substitution stream, not the update stream: kernel-trace / PMC scripts that pick "the update kernel's
+  // launches on the update stream" out of a bench run must not count these
+  hipStream_t sm = G.s_pred ? G.s_pred : G.s_main, sp = G.s_panel;
   Scratch sc;
   double *gA = nullptr, *gC = nullptr;
   unsigned long long* dclk = nullptr;
