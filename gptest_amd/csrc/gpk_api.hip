@@ -142,6 +142,8 @@ int gpk_set_option(const char* key, double value) {
     G.fuse_predict = v;
   } else if (k == "small_tile_below") {
     G.small_tile_below = v;
+  } else if (k == "tail_tile_kernel") {
+    G.tail_tile_kernel = v < 0 ? -1 : (v ? 1 : 0);
   } else if (k == "pred_defer_from") {
     if (v < -1 || (v > 0 && v % 128)) return gpk_set_err(-1, "option pred_defer_from=%d must be -1 (automatic), 0 (off) or a positive multiple of 128", v);
     G.pred_defer_from = v;
@@ -173,6 +175,7 @@ double gpk_get_option(const char* key) {
   if (k == "fuse_predict") return G.fuse_predict;
   if (k == "small_tile_below") return G.small_tile_below;
   if (k == "pred_defer_from") return G.pred_defer_from;
+  if (k == "tail_tile_kernel") return G.tail_tile_kernel;
   if (k == "graphs") return G.graphs;
   if (k == "stamps") return G.stamps;
   if (k == "timing") return G.timing;
@@ -725,7 +728,8 @@ int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, 
     GPK_HIP(hipMemcpy2DAsync(dB2, (size_t)k * 8, dB + k1, (size_t)k * 8, (size_t)k2 * 8, n, hipMemcpyDeviceToDevice, s));
     g.A2 = dA2; g.lda2 = k; g.B2 = dB2; g.ldb2 = k; g.k1 = k1;
   }
-  GPK_TRY(launch_gemm_nt(g, tile == 128, s));
+  if (tile == 16) GPK_TRY(launch_gemm_tile128(g, s));  // the chain's one-tile kernel (16x16 output tile per wave): m = n = k = 128 only
+  else GPK_TRY(launch_gemm_nt(g, tile == 128, s));
   GPK_HIP(hipMemcpyAsync(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipStreamSynchronize(s));
   return 0;

@@ -45,6 +45,7 @@ struct Runtime {
   int leaf_fat_rows = 6144;  // leaf_launch: the full-tile leaf once at most this many rows remain (option leaf_algo = 2)
   int pair_update = 1;    // two panels per trailing update (K doubled) for the far region: 0 never, 1 for Npad <= 8192, 2 always
   int fuse_predict = 1;   // bench / compute_prediction: overlap the prediction solve with the factorisation tail
+  int tail_tile_kernel = -1; // (-1: automatic, for Npad < 12288) tile pipeline: the two one-tile GEMMs of a step on the LDS-free 64-wave kernel instead of the 64x64-tile one
   int pred_defer_from = -1;  // (-1: automatic, 5/8 of the columns from Npad = 12288 on; 0: off) pipelined prediction: panels that end at or before this column update only the columns below it right away; their updates of the columns from it on are queued, in panel order, when the substitution reaches it (0: off)
   int small_tile_below = 256;  // panel_update: launches with fewer 128x128 tiles than this use the 64x64-tile kernel
   // launch graphs (fit_device, option graphs): the whole multi-stream enqueue of one fit (+ fused prediction) captured once

@@ -535,8 +535,15 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       t2.B = t2.A; t2.ldb = ld;
       t2.C = Acol + (long)128 * ldk + 128; t2.ldc = ldk;
       t2.m = 128; t2.n = 128; t2.k = 128; t2.sub = 1; t2.lower = 1;
-      GPK_TRY(launch_gemm_nt(t1, false, sc));
-      GPK_TRY(launch_gemm_nt(t2, false, sc));
+      // (automatic: where the whole factorisation is chain-bound, Npad < 12288 -- N = 4096 -6 %, 2048 -5 %, 8192 -2 %; at N = 16384
+      // the pipeline's steps are set by the substitution's catch-up GEMMs, the 64 priority waves of this kernel only delay those: +0.5 %)
+      if (G.tail_tile_kernel > 0 || (G.tail_tile_kernel < 0 && np_ < 12288)) {
+        GPK_TRY(launch_gemm_tile128(t1, sc));
+        GPK_TRY(launch_gemm_tile128(t2, sc));
+      } else {
+        GPK_TRY(launch_gemm_nt(t1, false, sc));
+        GPK_TRY(launch_gemm_nt(t2, false, sc));
+      }
       GPK_HIP(hipEventRecord(ev_tt[p], sc));
     }
     // ---- full-height panel GEMMs, in front of the bulk on the update stream

@@ -67,6 +67,8 @@ struct GemmNT {
 };
 // tile128 = true: the 8-wave 128x128-tile kernel (LDS-DMA staged); false: the 64x64-tile kernel (4 waves, 2x2 MFMA tiles each).
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s);
+// one 128 x 128 x 128 product on 64 waves without LDS (the chain's one-tile GEMMs); bitwise the other kernels
+int launch_gemm_tile128(const GemmNT& g, hipStream_t s);
 // the 8-wave kernel, with the XCD-aware tile order for the largest updates
 int launch_gemm_auto(const GemmNT& g, hipStream_t s);
 // ---------------------------------------------------------------- leaf factor

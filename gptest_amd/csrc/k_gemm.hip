@@ -203,6 +203,49 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ONE 128x128x128 product (the two one-tile GEMMs of a tile-pipeline step, which sit on the panel chain): 16 workgroups of
+// four waves, every wave owns one 16x16 output tile and reads its 32 + 32 operand values per lane straight from L2 -- no
+// LDS, no slab loop, no barrier: one load latency, then 32 MFMAs.  Same MFMA order over k, accumulators started from C,
+// A negated by an exact multiplication as in the 64x64-tile kernel: the same bits.  lower: only the 16x16 tiles that
+// touch the lower triangle (the leaf reads nothing above the diagonal).
+__global__ __launch_bounds__(256) void gemm_tile128_kernel(GemmNT g) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ti = (int)(blockIdx.x >> 2) * 2 + (wv >> 1), tj = (int)(blockIdx.x & 3) * 2 + (wv & 1);
+  if (g.lower && tj > ti) return;
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
+  const double* Ap = g.A + (long)(ti * 16 + fr) * g.lda + fg;
+  const double* Bp = g.B + (long)(tj * 16 + fr) * g.ldb + fg;
+  double* Cp = g.C + (long)(ti * 16 + fg) * g.ldc + tj * 16 + fr;
+  double a[32], b[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) a[q] = Ap[4 * q];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) b[q] = Bp[4 * q];
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  if (g.sub) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Cp[(long)(4 * r) * g.ldc];
+  }
+  const double sgn = g.sub ? -1.0 : 1.0;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * a[q], b[q], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Cp[(long)(4 * r) * g.ldc] = acc[r];
+}
+
+int launch_gemm_tile128(const GemmNT& g, hipStream_t s) {
+  if (g.m != 128 || g.n != 128 || g.k != 128 || g.cyc_P != 0 || g.k1 != 0)
+    return gpk_set_err(-1, "gemm_tile128: one 128 x 128 x 128 product only (m=%d n=%d k=%d)", g.m, g.n, g.k);
+  GemmNT h = g;
+  h.prio = (s == g_chain_stream) ? 1 : 0;
+  hipLaunchKernelGGL(gemm_tile128_kernel, dim3(16), dim3(256), 0, s, h);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // 8-wave 128x128-tile kernel: wave tile 64x32 (4x2 MFMA tiles, 64 accumulator VGPRs), <=104 VGPRs per wave, two
 // workgroups per CU = FOUR waves per SIMD in two independent barrier domains.  The matrix pipe itself is saturated by ONE
 // wave per SIMD (gpk_bench_mfma_pinned: 98-99 % of 2048 flop / 64 cycles / SIMD at W = 1, 2, 4, 8); what the second

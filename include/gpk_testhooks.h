@@ -29,7 +29,8 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
 /* ---- kernel-level test hooks (tests/ only; host buffers, row-major) --------- */
 /* C (m x n) = [C -] A (m x k) * B (n x k)^T through the MFMA kernels; tile = 128 (8-wave LDS-DMA kernel) or 64 (the
  * 4-wave kernel: its independent bit-for-bit cross-check).  k1 > 0: the K range split at column k1 over two separately
- * stored operands (the paired trailing update).  xcd_order: force the XCD-aware 8x8-square tile order (tile = 128). */
+ * stored operands (the paired trailing update).  xcd_order: force the XCD-aware 8x8-square tile order (tile = 128).
+ * tile = 16: the LDS-free one-tile kernel of the panel chain (m = n = k = 128 only; lower: the 16x16 tiles that touch the lower triangle). */
 int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile, int k1,
                      int xcd_order);
 /* the RCCL calls of the multi-rank path (broadcast on the panel stream, all-gather and all-reduce on the update

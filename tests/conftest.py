@@ -30,7 +30,7 @@ def golden_cases():
 
 # every option gpk_set_option knows (16 keys: 15 schedule switches + the launch-graph switch)
 OPTION_KEYS = ["nb", "nb_big_until", "nb_small_from", "nb_outer", "outer_until", "lookahead", "dist_group", "tail_rows",
-               "leaf_fat_rows", "gemm_polite", "pair_update", "fuse_predict", "small_tile_below", "pred_defer_from", "graphs", "stamps", "timing"]
+               "leaf_fat_rows", "gemm_polite", "pair_update", "fuse_predict", "small_tile_below", "pred_defer_from", "tail_tile_kernel", "graphs", "stamps", "timing"]
 
 
 @pytest.fixture(autouse=True)

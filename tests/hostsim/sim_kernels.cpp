@@ -51,6 +51,24 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t) {
   return 0;
 }
 
+// the one-tile kernel of the chain: 16x16 tiles that touch the lower triangle only (lower), exactly the elements the kernel touches
+int launch_gemm_tile128(const GemmNT& g, hipStream_t) {
+  if (g.m != 128 || g.n != 128 || g.k != 128 || g.cyc_P != 0 || g.k1 != 0) return gpk_set_err(-1, "gemm_tile128: one 128 x 128 x 128 product only");
+  for (int ti = 0; ti < 8; ++ti)
+    for (int tj = 0; tj < 8; ++tj) {
+      if (g.lower && tj > ti) continue;
+      for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+          const long ra = ti * 16 + i, rb = tj * 16 + j;
+          double acc = 0.0;
+          for (int kk = 0; kk < 128; ++kk) acc += g.A[ra * g.lda + kk] * g.B[rb * g.ldb + kk];
+          double* c = g.C + ra * g.ldc + rb;
+          *c = g.sub ? *c - acc : acc;
+        }
+    }
+  return 0;
+}
+
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, int, hipStream_t, int) {
   static thread_local double t[128][128], inv[128][128];
   for (int i = 0; i < 128; ++i)

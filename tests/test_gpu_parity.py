@@ -122,6 +122,33 @@ def test_tile_sizes_round_identically(gpk, sub):
     np.testing.assert_array_equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("sub,lower", [(0, 0), (1, 0), (1, 1)])
+def test_one_tile_chain_kernel_is_bitwise_the_tile_kernels(gpk, sub, lower):
+    """gemm_tile128_kernel (the two one-tile GEMMs of a tile-pipeline step: 64 waves, one 16x16 output tile each, operands
+    straight from L2, no LDS) accumulates over k in the order of the other kernels: its 128 x 128 x 128 product must be the
+    very bits of the 64x64-tile kernel's; with `lower` it leaves every 16x16 tile above the diagonal untouched."""
+    rng = np.random.RandomState(5 + sub + 2 * lower)
+    A = rng.randn(128, 128)
+    B = A.copy() if lower else rng.randn(128, 128)
+    C0 = rng.randn(128, 128)
+    out = {}
+    for tile in (16, 64, 128):
+        C = C0.copy()
+        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 128, 128, 128, sub, lower, tile, 0, 0) == 0, gpk.last_error()
+        out[tile] = C
+    touched = np.ones((128, 128), bool)
+    if lower:
+        for ti in range(8):
+            touched[ti * 16:(ti + 1) * 16, (ti + 1) * 16:] = False
+    assert np.array_equal(out[16][touched], out[64][touched]) and np.array_equal(out[16][touched], out[128][touched])
+    assert np.array_equal(out[16][~touched], C0[~touched])
+    ref = C0 - A @ B.T if sub else A @ B.T
+    np.testing.assert_allclose(out[16][touched], ref[touched], rtol=1e-12, atol=1e-12)
+    # anything but one 128 x 128 x 128 product is refused
+    C = np.zeros((256, 128))
+    assert gpk.lib().gpk_test_gemm_nt(_ptr(rng.randn(256, 128)), _ptr(B), _ptr(C), 256, 128, 128, 0, 0, 16, 0, 0) != 0
+
+
 @pytest.mark.parametrize("m,n,k,k1,lower", [(256, 384, 256, 128, 0), (512, 512, 384, 256, 1), (2048, 2048, 768, 512, 1)])
 def test_two_segment_k_is_bitwise_one_update(gpk, m, n, k, k1, lower):
     """The paired trailing update reads its K range from two separately stored panels; the result must be the
@@ -1380,6 +1407,7 @@ def test_gpy_compat_optimize_uses_the_device_gradient(gpk):
     {"nb_outer": 1024, "outer_until": 0, "fuse_predict": 0},
     {"nb_outer": 0},
     {"nb": 128, "tail_rows": 1 << 30},                                              # tile pipeline for everything
+    {"nb": 128, "tail_rows": 1 << 30, "tail_tile_kernel": 0},                       # ... with its one-tile GEMMs on the 64x64-tile kernel
     {"nb_small_from": 1024, "tail_rows": 1024},                                     # ... for the last 1024 columns
 ])
 def test_option_paths_keep_parity(gpk, opts):
