@@ -1,4 +1,4 @@
-"""ctypes binding of libgpk.so (the C-ABI declared in include/gpk.h).
+"""ctypes binding of libgpk.so (the C-ABI declared in include/gpk.h, plus bench.py's measurement entry points of include/gpk_bench.h).
 
 The product path fails loudly: no NumPy/CPU fallback exists anywhere in this
 package.  ``lib()`` raises ``GpkError`` when the shared library is not built and
@@ -63,22 +63,10 @@ def _bind(l):
         "gpk_append": (i, [c_void_pp, dp, dp, i, dp]),
         "gpk_class_laplace": (i, [vp, dp, i, dp, d, i, dp, ctypes.POINTER(ctypes.c_int), dp]),
         "gpk_class_predict": (i, [vp, dp, i, dp, dp, i, dp, dp, dp]),
-        "gpk_test_rccl_selfcheck": (i, [i]),
         "gpk_last_timing": (i, [cp, dp, dp]),
         "gpk_last_timing_work": (i, [cp, dp]),
         "gpk_bench_posterior": (i, [dp, dp, i, i, dp, dp, i, i, i, dp, dp, dp, dp]),
-        "gpk_test_gemm_nt": (i, [dp, dp, dp, i, i, i, i, i, i, i, i]),
-        "gpk_test_potf2_128": (i, [dp, dp, dp, i]),
-        "gpk_test_dist_potrf": (i, [dp, i, i, dp]),
-        "gpk_test_dist_fit": (i, [dp, i, i, dp, d, i, dp]),
-        "gpk_test_dist_posterior": (i, [dp, dp, i, i, dp, dp, i, i, dp, dp, dp]),
-        "gpk_bench_se_build": (i, [i, i, i, i, i, dp]),
-        "gpk_bench_gemm_nt": (i, [i, i, i, i, i, i, dp]),
         "gpk_bench_mfma_pinned": (i, [i, i, dp]),
-        "gpk_bench_lds_bank_probe": (i, [i, i]),
-        "gpk_bench_leaf": (i, [i, i, dp]),
-        "gpk_bench_leaf_contended": (i, [i, dp, dp]),
-        "gpk_bench_chain_step": (i, [i, i, i, dp, dp]),
         "gpk_bench_clock_under_load": (i, [i, i, i, i, dp, dp]),
     }
     for name, (res, args) in sig.items():

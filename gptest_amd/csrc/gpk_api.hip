@@ -1,7 +1,7 @@
 // extern "C" surface of libgpk.so (see include/gpk.h for the contract and the
 // reference file:line each entry point replaces).
 #include "../../include/gpk.h"
-#include "../../include/gpk_testhooks.h"
+#include "../../include/gpk_bench.h"
 #include "gpk_core.h"
 #include <cmath>
 #include <map>
@@ -52,6 +52,10 @@ int gpk_init(int device) {
     GPK_HIP(hipMalloc((void**)&g_cu_guest, GPK_GUEST_SLOTS * sizeof(unsigned)));
     GPK_HIP(hipMemset(g_cu_guest, 0, GPK_GUEST_SLOTS * sizeof(unsigned)));
   }
+  if (!G.dctr) {
+    GPK_HIP(hipMalloc((void**)&G.dctr, 64 * sizeof(unsigned)));
+    GPK_HIP(hipMemset(G.dctr, 0, 64 * sizeof(unsigned)));
+  }
   G.device = device;
   {
     // One launch per stream: the runtime builds a stream's hardware queue lazily, so the first real launch on each
@@ -83,6 +87,8 @@ void gpk_shutdown(void) {
   G.hstamps.clear();
   if (g_cu_guest) (void)hipFree(g_cu_guest);
   g_cu_guest = nullptr;
+  if (G.dctr) (void)hipFree(G.dctr);
+  G.dctr = nullptr;
   graph_cache_clear();
   for (auto& kv : G.hpin_pool)
     for (double* q : kv.second) (void)hipHostFree(q);
@@ -92,7 +98,8 @@ void gpk_shutdown(void) {
   G.ev_free.clear();
   for (hipEvent_t e : G.ev_dep_free) (void)hipEventDestroy(e);
   G.ev_dep_free.clear();
-  for (hipStream_t* sp : {&G.s_pred, &G.s_comm, &G.s_panel, &G.s_main}) {
+  G.s_corner_prio = -1;
+  for (hipStream_t* sp : {&G.s_corner, &G.s_pred, &G.s_comm, &G.s_panel, &G.s_main}) {
     if (*sp) (void)hipStreamDestroy(*sp);
     *sp = nullptr;
   }
@@ -147,6 +154,27 @@ int gpk_set_option(const char* key, double value) {
   } else if (k == "pred_defer_from") {
     if (v < -1 || (v > 0 && v % 128)) return gpk_set_err(-1, "option pred_defer_from=%d must be -1 (automatic), 0 (off) or a positive multiple of 128", v);
     G.pred_defer_from = v;
+  } else if (k == "corner_from") {
+    if (v < -1 || (v > 0 && v % 128)) return gpk_set_err(-1, "option corner_from=%d must be -1 (automatic), 0 (off) or a positive multiple of 128", v);
+    G.corner_from = v;
+  } else if (k == "corner_from2" || k == "corner_from3") {
+    if (v < 0 || v % 128) return gpk_set_err(-1, "option %s=%d must be 0 (none) or a positive multiple of 128", k.c_str(), v);
+    (k == "corner_from2" ? G.corner_from2 : G.corner_from3) = v;
+  } else if (k == "corner_chunk") {
+    if (v < 128 || v % 128) return gpk_set_err(-1, "option corner_chunk=%d must be a positive multiple of 128", v);
+    G.corner_chunk = v;
+  } else if (k == "corner_last") {
+    if (v < 0 || v % 128) return gpk_set_err(-1, "option corner_last=%d must be a multiple of 128", v);
+    G.corner_last = v;
+  } else if (k == "corner_grid") {
+    if (v < 0 || v > 4096) return gpk_set_err(-1, "option corner_grid=%d must be in 0..4096", v);
+    G.corner_grid = v;
+  } else if (k == "corner_hold") {
+    if (v < 0 || v % 128) return gpk_set_err(-1, "option corner_hold=%d must be a multiple of 128", v);
+    G.corner_hold = v;
+  } else if (k == "corner_prio") {
+    if (v < 0 || v > 2) return gpk_set_err(-1, "option corner_prio=%d must be 0, 1 or 2", v);
+    G.corner_prio = v;
   } else if (k == "graphs") {
     G.graphs = v ? 1 : 0;
   } else if (k == "stamps") {
@@ -176,6 +204,17 @@ double gpk_get_option(const char* key) {
   if (k == "small_tile_below") return G.small_tile_below;
   if (k == "pred_defer_from") return G.pred_defer_from;
   if (k == "tail_tile_kernel") return G.tail_tile_kernel;
+  if (k == "corner_from") return G.corner_from;
+  if (k == "corner_chunk") return G.corner_chunk;
+  if (k == "corner_last") return G.corner_last;
+  if (k == "corner_prio") return G.corner_prio;
+  if (k == "corner_hold") return G.corner_hold;
+  if (k == "corner_grid") return G.corner_grid;
+  if (k == "corner_from2") return G.corner_from2;
+  if (k == "corner_from3") return G.corner_from3;
+  if (k == "potrf_corner_from") return g_potrf_corner[0];
+  if (k == "potrf_corner_from2") return g_potrf_corner[1];
+  if (k == "potrf_corner_from3") return g_potrf_corner[2];
   if (k == "graphs") return G.graphs;
   if (k == "stamps") return G.stamps;
   if (k == "timing") return G.timing;
@@ -191,10 +230,10 @@ double gpk_get_option(const char* key) {
   if (k == "potrf_tail_from") { extern int g_potrf_tail_from; return g_potrf_tail_from; }
   // diagnostic stamps of the last fused fit: "stamp_panel_<p>" / "stamp_subst_<p>" in ms after panel 0
   if (k.rfind("stamp_", 0) == 0 && G.hstamps.size() == 1024 && G.hstamps[0]) {
-    const bool subst = k.rfind("stamp_subst_", 0) == 0;
-    const int p = atoi(k.c_str() + 12);
-    if (p < 0 || p >= 512) return NAN;
-    const unsigned long long v = G.hstamps[(subst ? 512 : 0) + p];
+    const bool subst = k.rfind("stamp_subst_", 0) == 0, corner = k.rfind("stamp_corner", 0) == 0;  // "stamp_corner_<j>": catch-up launch j of the lazy corner done
+    const int p = atoi(k.c_str() + (corner ? 13 : 12));
+    if (p < 0 || p >= (corner ? 64 : 448)) return NAN;
+    const unsigned long long v = G.hstamps[(subst ? 512 : corner ? 448 : 0) + p];
     return v ? (double)((long long)(v - G.hstamps[0])) * 1e-5 : NAN;
   }
   return NAN;
@@ -256,7 +295,16 @@ __global__ void pad_identity_kernel(double* K, long ld, int N, int Npad) {
   }
 }
 
-static int model_unpack_L(gpk_model* m, double* L_out_host) {
+}  // extern "C"
+
+// (shared with the hooks library: C++ linkage, declared in gpk_core.h)
+int launch_pad_identity(double* K, long ld, int N, int Npad, hipStream_t s) {
+  hipLaunchKernelGGL(pad_identity_kernel, dim3(1024), dim3(256), 0, s, K, ld, N, Npad);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+int model_unpack_L(gpk_model* m, double* L_out_host) {
   hipStream_t s = G.s_main;
   const int N = m->N;
   double* dOut = nullptr;
@@ -271,6 +319,8 @@ static int model_unpack_L(gpk_model* m, double* L_out_host) {
   dev_free(dOut, (size_t)N * N * 8);
   return rc;
 }
+
+extern "C" {
 
 int gpk_potrf(double* A, int N) {
   if (!A) return gpk_set_err(-1, "gpk_potrf: null pointer");
@@ -630,194 +680,8 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
 
 }  // extern "C"
 
-// ---------------------------------------------------------------- kernel-level test hooks
-__global__ void pad_diag_local_kernel(double* K, long ldk, int N, int Npad, int OB, int P, int r) {
-  // ones on the padded diagonal entries (i >= N) that fall into this rank's ownership blocks (width OB)
-  for (int i = N + blockIdx.x * blockDim.x + threadIdx.x; i < Npad; i += gridDim.x * blockDim.x) {
-    const int g = i / OB;
-    if (g % P == r) K[(long)i * ldk + (long)(g / P) * OB + (i % OB)] = 1.0;
-  }
-}
-
-extern "C" {
-
-// Single-GPU emulation of a P-rank block-cyclic job: P rank models live in this process and are driven through
-// the production group entry points (potrf_group / fit_group / predict_group), i.e. the very phases, stream and
-// event order a real rank runs; only the RCCL broadcast / all-gather are device copies from the peer's model.
-struct VirtualJob {
-  std::vector<gpk_model*> ms;
-  ~VirtualJob() {
-    for (gpk_model* m : ms)
-      if (m) model_destroy(m);
-  }
-  int create(int N, int d, int P) {
-    ms.assign(P, nullptr);
-    for (int r = 0; r < P; ++r) GPK_TRY(model_create(&ms[r], N, d, false, P, r));
-    for (int r = 0; r < P; ++r) ms[r]->vgroup = ms.data();
-    return 0;
-  }
-};
-
-static int virtual_job_check_info(VirtualJob& job, int N) {
-  hipStream_t s = G.s_main;
-  int worst = 0;
-  for (gpk_model* m : job.ms) {
-    int hinfo = 0;
-    GPK_HIP(hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s));
-    GPK_HIP(hipStreamSynchronize(s));
-    if (hinfo > worst) worst = hinfo;
-  }
-  if (worst > 0) return worst > N ? N : worst;
-  return 0;
-}
-
-// L of rank P-1 is returned.  P = 1 is the production single-GPU factorisation (potrf_device).
-int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
-  GPK_TRY(rt_require());
-  if (!A || !L_out || N < 1 || P < 1 || P > 16) return gpk_set_err(-1, "gpk_test_dist_potrf: bad arguments");
-  hipStream_t s = G.s_main;
-  VirtualJob job;
-  GPK_TRY(job.create(N, 1, P));
-  const int OB = job.ms[0]->OB, np_ = job.ms[0]->Npad;
-  for (int r = 0; r < P; ++r) {
-    gpk_model* m = job.ms[r];
-    GPK_HIP(hipMemsetAsync(m->dK, 0, (size_t)np_ * m->ldk * 8, s));
-    if (P == 1) {
-      GPK_HIP(hipMemcpy2DAsync(m->dK, (size_t)m->ldk * 8, A, (size_t)N * 8, (size_t)N * 8, N, hipMemcpyHostToDevice, s));
-      if (np_ > N) hipLaunchKernelGGL(pad_identity_kernel, dim3(1024), dim3(256), 0, s, m->dK, m->ldk, N, np_);
-      continue;
-    }
-    for (int lb = 0; lb < m->nloc; ++lb) {
-      const int cg0 = (lb * P + r) * OB;
-      const int nc = std::min(OB, N - cg0);
-      if (nc <= 0) continue;
-      GPK_HIP(hipMemcpy2DAsync(m->dK + (size_t)lb * OB, (size_t)m->ldk * 8, A + cg0, (size_t)N * 8, (size_t)nc * 8, N,
-                               hipMemcpyHostToDevice, s));
-    }
-    if (np_ > N) hipLaunchKernelGGL(pad_diag_local_kernel, dim3(8), dim3(256), 0, s, m->dK, m->ldk, N, np_, OB, P, r);
-  }
-  GPK_TRY(P == 1 ? potrf_device(job.ms[0]) : potrf_group(job.ms.data(), P));
-  GPK_TRY(virtual_job_check_info(job, N));
-  return model_unpack_L(job.ms[P - 1], L_out);
-}
-
-int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile, int k1,
-                     int xcd_order) {
-  GPK_TRY(rt_require());
-  if (!A || !B || !C || m < 1 || n < 1 || k < 1) return gpk_set_err(-1, "gpk_test_gemm_nt: bad arguments");
-  hipStream_t s = G.s_main;
-  Scratch sc;
-  double *dA = nullptr, *dB = nullptr, *dC = nullptr, *dA2 = nullptr, *dB2 = nullptr;
-  GPK_TRY(sc.get(&dA, (size_t)m * k));
-  GPK_TRY(sc.get(&dB, (size_t)n * k));
-  GPK_TRY(sc.get(&dC, (size_t)m * n));
-  GPK_HIP(hipMemcpyAsync(dA, A, (size_t)m * k * 8, hipMemcpyHostToDevice, s));
-  GPK_HIP(hipMemcpyAsync(dB, B, (size_t)n * k * 8, hipMemcpyHostToDevice, s));
-  GPK_HIP(hipMemcpyAsync(dC, C, (size_t)m * n * 8, hipMemcpyHostToDevice, s));
-  GemmNT g{};
-  g.A = dA; g.lda = k; g.B = dB; g.ldb = k; g.C = dC; g.ldc = n;
-  g.m = m; g.n = n; g.k = k; g.sub = sub; g.lower = lower;
-  g.xcd_sq = (xcd_order && tile == 128) ? 1 : 0;  // force the XCD-aware 8x8-square tile order of the largest updates
-  if (k1 > 0 && k1 < k) {
-    // same product with the K range split over two separately stored operands (the paired trailing update);
-    // second segment stored separately but with the same leading dimension k (columns [0, k2) used)
-    const int k2 = k - k1;
-    GPK_TRY(sc.get(&dA2, (size_t)m * k));
-    GPK_TRY(sc.get(&dB2, (size_t)n * k));
-    GPK_HIP(hipMemcpy2DAsync(dA2, (size_t)k * 8, dA + k1, (size_t)k * 8, (size_t)k2 * 8, m, hipMemcpyDeviceToDevice, s));
-    GPK_HIP(hipMemcpy2DAsync(dB2, (size_t)k * 8, dB + k1, (size_t)k * 8, (size_t)k2 * 8, n, hipMemcpyDeviceToDevice, s));
-    g.A2 = dA2; g.lda2 = k; g.B2 = dB2; g.ldb2 = k; g.k1 = k1;
-  }
-  if (tile == 16) GPK_TRY(launch_gemm_tile128(g, s));  // the chain's one-tile kernel (16x16 output tile per wave): m = n = k = 128 only
-  else GPK_TRY(launch_gemm_nt(g, tile == 128, s));
-  GPK_HIP(hipMemcpyAsync(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost, s));
-  GPK_HIP(hipStreamSynchronize(s));
-  return 0;
-}
-
-int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out, int full_tile) {
-  GPK_TRY(rt_require());
-  hipStream_t s = G.s_main;
-  double *dA = nullptr, *dL = nullptr, *dD = nullptr;
-  int* dinfo = nullptr;
-  GPK_TRY(dev_alloc_t(&dA, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dL, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dD, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dinfo, 4));
-  int rc = 0, hinfo = 0;
-  do {
-    if (hipMemcpyAsync(dA, A, 128 * 128 * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    if (hipMemsetAsync(dinfo, 0, 16, s) != hipSuccess) { rc = gpk_set_err(-2, "memset failed"); break; }
-    rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, 0, s, full_tile ? 1 : 0);
-    if (rc) break;
-    if (hipMemcpyAsync(L_out, dL, 128 * 128 * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-    if (hipMemcpyAsync(Dinv_out, dD, 128 * 128 * 8, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-    if (hipMemcpyAsync(&hinfo, dinfo, 4, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-    if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "test_potf2: %s", hipGetErrorString(hipGetLastError())); break; }
-    rc = hinfo;
-  } while (0);
-  dev_free(dA, 128 * 128 * 8);
-  dev_free(dL, 128 * 128 * 8);
-  dev_free(dD, 128 * 128 * 8);
-  dev_free(dinfo, 16);
-  return rc;
-}
-
-}  // extern "C"
-
-extern "C" int gpk_test_dist_fit(const double* X, int N, int d, const double* log_hyp, double jitter, int P, double* L_out) {
-  // as gpk_test_dist_potrf, but every virtual rank builds ITS block columns of K from X (build_K), which
-  // exercises the global-column bookkeeping of the kernel-matrix builder.
-  GPK_TRY(rt_require());
-  if (!X || !log_hyp || !L_out || N < 1 || P < 1 || P > 16) return gpk_set_err(-1, "gpk_test_dist_fit: bad arguments");
-  hipStream_t s = G.s_main;
-  VirtualJob job;
-  GPK_TRY(job.create(N, d, P));
-  for (gpk_model* m : job.ms) {
-    GPK_TRY(decode_hyp(log_hyp, d, jitter, m));
-    GPK_HIP(hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s));
-  }
-  GPK_TRY(P == 1 ? fit_device(job.ms[0]) : fit_group(job.ms.data(), P));
-  return model_unpack_L(job.ms[P - 1], L_out);
-}
-
-// The whole posterior of a P-rank job (fit + sharded prediction + emulated all-gather) on P virtual ranks.
-// nlml_out[P], mean_out / var_out [P][M]: what every rank ends up with (they must all agree).
-extern "C" int gpk_test_dist_posterior(const double* X, const double* y, int N, int d, const double* log_hyp,
-                                       const double* Z, int M, int P, double* nlml_out, double* mean_out,
-                                       double* var_out) {
-  GPK_TRY(rt_require());
-  if (!X || !y || !log_hyp || !Z || !nlml_out || !mean_out || !var_out || N < 1 || M < 1 || P < 2 || P > 16)
-    return gpk_set_err(-1, "gpk_test_dist_posterior: bad arguments");
-  hipStream_t s = G.s_main;
-  VirtualJob job;
-  GPK_TRY(job.create(N, d, P));
-  double* dZ = nullptr;
-  GPK_TRY(dev_alloc_t(&dZ, (size_t)M * d));
-  auto body = [&]() -> int {
-    GPK_HIP(hipMemcpyAsync(dZ, Z, (size_t)M * d * 8, hipMemcpyHostToDevice, s));
-    for (gpk_model* m : job.ms) {
-      GPK_TRY(decode_hyp(log_hyp, d, 0.0, m));
-      m->has_y = true;
-      GPK_HIP(hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s));
-      GPK_HIP(hipMemsetAsync(m->dy, 0, (size_t)m->Npad * 8, s));
-      GPK_HIP(hipMemcpyAsync(m->dy, y, (size_t)N * 8, hipMemcpyHostToDevice, s));
-    }
-    GPK_TRY(fit_group(job.ms.data(), P));
-    std::vector<double*> hm(P), hv(P);
-    for (int r = 0; r < P; ++r) {
-      nlml_out[r] = job.ms[r]->nlml;
-      hm[r] = mean_out + (size_t)r * M;
-      hv[r] = var_out + (size_t)r * M;
-    }
-    return predict_group(job.ms.data(), P, dZ, M, hm.data(), hv.data());
-  };
-  int rc = body();
-  if (rc) (void)hipStreamSynchronize(s);
-  dev_free(dZ, (size_t)M * d * 8);
-  return rc;
-}
-
+// ---------------------------------------------------------------- the two hardware probes bench.py prints next to its roofline
+// (every other gpk_bench_* / gpk_test_* hook lives in gpk_hooks.hip -> libgpk_hooks.so, which tests/ and scripts/ load)
 #ifndef GPK_HOSTSIM  // device-only probes (MFMA builtins, hardware registers): not part of the host-side sanitizer build
 // ---------------------------------------------------------------- micro-benchmarks
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -928,144 +792,7 @@ int gpk_bench_mfma_pinned(int waves_per_simd, int iters, double* out) {
 
 }  // extern "C"
 
-// LDS banking probe: every lane issues `reps` ds_read_b64 from one fixed address given by `pattern`; run under
-// `rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE` (scripts/lds_bank_probe.sh).  fr = lane & 15, fg = lane >> 4 as in
-// the MFMA operand layout.  0: lane * 8 (contiguous); 1: the LDS-DMA image of the tile kernel (128-byte rows, 16-byte chunks
-// XOR-swizzled by (row >> 1) & 7, k = fg); 2: rows 18 doubles apart (the register-staged image); 3: rows 17 doubles apart;
-// 4: 128-byte rows with an 8-byte swizzle ((fr & 7) * 2 + ((fr >> 3) ^ (fg & 1))); 5: pattern 1 without the swizzle.
-template <int PAT>
-__global__ __launch_bounds__(256) void lds_bank_probe_kernel(double* out, int reps) {
-  __shared__ double buf[64 * 18 + 64];
-  for (int e = threadIdx.x; e < 64 * 18 + 64; e += 256) buf[e] = (double)e;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
-  int idx;
-  if (PAT == 0) idx = lane;
-  else if (PAT == 1) idx = fr * 16 + ((((fg >> 1) ^ ((fr >> 1) & 7)) * 2) + (fg & 1));
-  else if (PAT == 2) idx = fr * 18 + fg;
-  else if (PAT == 3) idx = fr * 17 + fg;
-  else if (PAT == 4) idx = fr * 16 + (((fr & 7) * 2 + ((fr >> 3) ^ (fg & 1))) ^ ((fg >> 1) * 2)) % 16;
-  else idx = fr * 16 + fg;
-  const double* p = buf + idx;
-  double acc = 0;
-  for (int r = 0; r < reps; ++r) {
-    double v;
-    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(unsigned long)(__attribute__((address_space(3))) const double*)p) : "memory");
-    acc += v;
-  }
-  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
-}
-
 extern "C" {
-
-int gpk_bench_lds_bank_probe(int pattern, int reps) {
-  GPK_TRY(rt_require());
-  Scratch sc;
-  double* d = nullptr;
-  GPK_TRY(sc.get(&d, (size_t)256 * 256));
-  hipStream_t s = G.s_main;
-  switch (pattern) {
-    case 0: hipLaunchKernelGGL(lds_bank_probe_kernel<0>, dim3(256), dim3(256), 0, s, d, reps); break;
-    case 1: hipLaunchKernelGGL(lds_bank_probe_kernel<1>, dim3(256), dim3(256), 0, s, d, reps); break;
-    case 2: hipLaunchKernelGGL(lds_bank_probe_kernel<2>, dim3(256), dim3(256), 0, s, d, reps); break;
-    case 3: hipLaunchKernelGGL(lds_bank_probe_kernel<3>, dim3(256), dim3(256), 0, s, d, reps); break;
-    case 4: hipLaunchKernelGGL(lds_bank_probe_kernel<4>, dim3(256), dim3(256), 0, s, d, reps); break;
-    default: hipLaunchKernelGGL(lds_bank_probe_kernel<5>, dim3(256), dim3(256), 0, s, d, reps); break;
-  }
-  GPK_HIP(hipGetLastError());
-  GPK_HIP(hipStreamSynchronize(s));
-  return 0;
-}
-
-int gpk_bench_leaf(int dbg_skip, int reps, double* us_out) {
-  GPK_TRY(rt_require());
-  hipStream_t s = G.s_main;
-  double *dA = nullptr, *dL = nullptr, *dD = nullptr;
-  int* dinfo = nullptr;
-  GPK_TRY(dev_alloc_t(&dA, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dL, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dD, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dinfo, 4));
-  std::vector<double> h(128 * 128);
-  for (int i = 0; i < 128; ++i)
-    for (int j = 0; j < 128; ++j) h[i * 128 + j] = (i == j ? 4.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
-  GPK_HIP(hipMemcpyAsync(dA, h.data(), 128 * 128 * 8, hipMemcpyHostToDevice, s));
-  GPK_HIP(hipMemsetAsync(dinfo, 0, 16, s));
-  const int fat = (dbg_skip >> 8) & 1;  // bit 8: the full-tile form
-  dbg_skip &= 0xff;
-  int rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg_skip, s, fat);
-  hipEvent_t e0, e1;
-  GPK_HIP(hipEventCreate(&e0));
-  GPK_HIP(hipEventCreate(&e1));
-  GPK_HIP(hipEventRecord(e0, s));
-  for (int r = 0; r < reps && !rc; ++r) rc = launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg_skip, s, fat);
-  GPK_HIP(hipEventRecord(e1, s));
-  GPK_HIP(hipEventSynchronize(e1));
-  float ms = 0;
-  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
-  if (us_out) *us_out = 1e3 * ms / reps;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  dev_free(dA, 128 * 128 * 8);
-  dev_free(dL, 128 * 128 * 8);
-  dev_free(dD, 128 * 128 * 8);
-  dev_free(dinfo, 16);
-  return rc;
-}
-
-// leaf kernel on the chain stream while the update stream keeps the chip busy (reps bit 24: the full-tile form)
-int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended) {
-  const int fat = (reps >> 24) & 1;
-  const int dbg = (reps >> 16) & 0xff;  // leaf dbg_skip mode
-  reps &= 0xffff;
-  GPK_TRY(rt_require());
-  hipStream_t sl = G.s_panel ? G.s_panel : G.s_main, sm = G.s_main;
-  double *dA = nullptr, *dL = nullptr, *dD = nullptr, *gA = nullptr, *gC = nullptr;
-  int* dinfo = nullptr;
-  const int gm = 8192, gk = 256;
-  GPK_TRY(dev_alloc_t(&dA, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dL, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dD, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dinfo, 4));
-  GPK_TRY(dev_alloc_t(&gA, (size_t)gm * gk));
-  GPK_TRY(dev_alloc_t(&gC, (size_t)gm * gm));
-  std::vector<double> h(128 * 128);
-  for (int i = 0; i < 128; ++i)
-    for (int j = 0; j < 128; ++j) h[i * 128 + j] = (i == j ? 4.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
-  GPK_HIP(hipMemcpy(dA, h.data(), 128 * 128 * 8, hipMemcpyHostToDevice));
-  GPK_HIP(hipMemset(dinfo, 0, 16));
-  GPK_TRY(launch_fill(gA, (size_t)gm * gk, 1e-3, sm));
-  GPK_TRY(launch_fill(gC, (size_t)gm * gm, 1.0, sm));
-  GPK_HIP(hipDeviceSynchronize());
-  hipEvent_t e0, e1;
-  GPK_HIP(hipEventCreate(&e0));
-  GPK_HIP(hipEventCreate(&e1));
-  auto run_leaves = [&](double* out) -> int {
-    GPK_HIP(hipEventRecord(e0, sl));
-    for (int r = 0; r < reps; ++r) GPK_TRY(launch_potf2_trtri_128(dA, 128, dL, 128, dD, dinfo, 0, dbg, sl, fat));
-    GPK_HIP(hipEventRecord(e1, sl));
-    GPK_HIP(hipEventSynchronize(e1));
-    float ms = 0;
-    GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *out = 1e3 * ms / reps;
-    int hi[8] = {0};
-    GPK_HIP(hipMemcpy(hi, dinfo, 32, hipMemcpyDeviceToHost));
-    if (dbg & 8) printf("   phases (us): load %.1f | eliminate+scale+L store %.1f | inverse %.1f | Dinv store issue %.1f\n", (hi[4]-hi[3])*0.01, (hi[5]-hi[4])*0.01, (hi[6]-hi[5])*0.01, (hi[7]-hi[6])*0.01);
-    if (dbg & 8) printf("   elimination: %d shader cycles, %d ticks of 10 ns -> %.3f GHz, %.1f us\n", hi[1], hi[2], hi[2] ? hi[1] / (hi[2] * 10.0) : 0.0, hi[2] * 0.01);
-    return 0;
-  };
-  GPK_TRY(run_leaves(us_alone));
-  GemmNT g{};
-  g.A = gA; g.lda = gk; g.B = gA; g.ldb = gk; g.C = gC; g.ldc = gm; g.m = gm; g.n = gm; g.k = gk; g.sub = 1; g.lower = 1;
-  for (int r = 0; r < 120; ++r) GPK_TRY(launch_gemm_nt(g, true, sm));  // ~15 ms of back-to-back trailing updates
-  GPK_TRY(run_leaves(us_contended));
-  GPK_HIP(hipDeviceSynchronize());
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  dev_free(dA, 128 * 128 * 8); dev_free(dL, 128 * 128 * 8); dev_free(dD, 128 * 128 * 8); dev_free(dinfo, 16);
-  dev_free(gA, (size_t)gm * gk * 8); dev_free(gC, (size_t)gm * gm * 8);
-  return 0;
-}
 
 // Is the chip clock-throttled under the sustained trailing update?  One wave on the panel-chain stream measures the
 // shader clock (s_memtime ticks per s_memrealtime tick x 100 MHz) over ~0.2 ms, `nsamp` times, while the update
@@ -1117,184 +844,6 @@ int gpk_bench_clock_under_load(int m, int k, int nbig, int nsamp, double* ghz_ou
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return 0;
-}
-
-// Feasibility probe for a tile-level critical chain: `reps` steps of [leaf, `nsmall` one-tile-row GEMMs (m = 128, n = 128,
-// k = 128, 64x64 tiles = 4 workgroups each)] on the panel-chain stream, alone and while the update stream runs
-// back-to-back trailing updates.  us per step.
-int gpk_bench_chain_step(int reps, int nsmall, int small_m, double* us_alone, double* us_contended) {
-  GPK_TRY(rt_require());
-  hipStream_t sl = G.s_panel, sm = G.s_main;
-  double *dA = nullptr, *dL = nullptr, *dD = nullptr, *gA = nullptr, *gC = nullptr, *tC = nullptr;
-  int* dinfo = nullptr;
-  const int gm = 8192, gk = 256;
-  GPK_TRY(dev_alloc_t(&dA, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dL, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dD, 128 * 128));
-  GPK_TRY(dev_alloc_t(&dinfo, 4));
-  GPK_TRY(dev_alloc_t(&gA, (size_t)gm * gk));
-  GPK_TRY(dev_alloc_t(&gC, (size_t)gm * gm));
-  GPK_TRY(dev_alloc_t(&tC, (size_t)small_m * 128));
-  std::vector<double> h(128 * 128);
-  for (int i = 0; i < 128; ++i)
-    for (int j = 0; j < 128; ++j) h[i * 128 + j] = (i == j ? 4.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
-  GPK_HIP(hipMemcpy(dA, h.data(), 128 * 128 * 8, hipMemcpyHostToDevice));
-  GPK_HIP(hipMemset(dinfo, 0, 16));
-  GPK_TRY(launch_fill(gA, (size_t)gm * gk, 1e-3, sm));
-  GPK_TRY(launch_fill(gC, (size_t)gm * gm, 1.0, sm));
-  GPK_TRY(launch_fill(tC, (size_t)small_m * 128, 1.0, sm));
-  GPK_HIP(hipDeviceSynchronize());
-  hipEvent_t e0, e1;
-  GPK_HIP(hipEventCreate(&e0));
-  GPK_HIP(hipEventCreate(&e1));
-  auto run_chain = [&](double* out) -> int {
-    GPK_HIP(hipEventRecord(e0, sl));
-    for (int r = 0; r < reps; ++r) {
-      GPK_TRY(leaf_launch(dA, 128, dL, 128, dD, dinfo, 0, sl));
-      for (int q = 0; q < nsmall; ++q) {
-        GemmNT g{};
-        g.A = gA; g.lda = gk; g.B = dD; g.ldb = 128; g.C = tC; g.ldc = 128;
-        g.m = small_m; g.n = 128; g.k = 128; g.sub = (q & 1);
-        GPK_TRY(launch_gemm_nt(g, false, sl));
-      }
-    }
-    GPK_HIP(hipEventRecord(e1, sl));
-    GPK_HIP(hipEventSynchronize(e1));
-    float ms = 0;
-    GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *out = 1e3 * ms / reps;
-    return 0;
-  };
-  {
-    GPK_TRY(run_chain(us_alone));
-    GemmNT g{};
-    g.A = gA; g.lda = gk; g.B = gA; g.ldb = gk; g.C = gC; g.ldc = gm; g.m = gm; g.n = gm; g.k = gk; g.sub = 1; g.lower = 1;
-    const int nbig = (int)(reps * 0.12) + 20;  // ~0.37 ms each: enough to outlast the chain
-    for (int r = 0; r < nbig; ++r) GPK_TRY(launch_gemm_nt(g, true, sm));
-    GPK_TRY(run_chain(us_contended));
-  }
-  GPK_HIP(hipDeviceSynchronize());
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  dev_free(dA, 128 * 128 * 8); dev_free(dL, 128 * 128 * 8); dev_free(dD, 128 * 128 * 8); dev_free(dinfo, 16);
-  dev_free(gA, (size_t)gm * gk * 8); dev_free(gC, (size_t)gm * gm * 8); dev_free(tC, (size_t)small_m * 128 * 8);
-  return 0;
-}
-
-// device-resident timing of the kernel-matrix builder: mode 0 SE, 1 squared distance, 2 stores only
-int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_out) {
-  GPK_TRY(rt_require());
-  hipStream_t s = G.s_main;
-  const int np_ = round_up(N, 128);
-  double *dX = nullptr, *dK = nullptr;
-  GPK_TRY(dev_alloc_t(&dX, (size_t)N * d));
-  GPK_TRY(dev_alloc_t(&dK, (size_t)np_ * np_));
-  std::vector<double> h((size_t)N * d);
-  unsigned long long st = 88172645463325252ull;
-  for (auto& v : h) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = (double)(st >> 11) / 9007199254740992.0; }
-  GPK_HIP(hipMemcpyAsync(dX, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
-  SEParams se{};
-  se.d = d; se.sf2 = 1.0; se.diag_add = 0.01;
-  for (int k = 0; k < d; ++k) se.ell[k] = 0.7;
-  int rc = launch_se_build(dX, N, np_, dX, N, np_, se, 1, mode, dK, np_, lower, s);
-  hipEvent_t e0, e1;
-  GPK_HIP(hipEventCreate(&e0));
-  GPK_HIP(hipEventCreate(&e1));
-  GPK_HIP(hipEventRecord(e0, s));
-  for (int r = 0; r < reps && !rc; ++r) rc = launch_se_build(dX, N, np_, dX, N, np_, se, 1, mode, dK, np_, lower, s);
-  GPK_HIP(hipEventRecord(e1, s));
-  GPK_HIP(hipEventSynchronize(e1));
-  float ms = 0;
-  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
-  if (ms_out) *ms_out = ms / reps;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  dev_free(dX, (size_t)N * d * 8);
-  dev_free(dK, (size_t)np_ * np_ * 8);
-  return rc;
-}
-
-int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out) {
-  GPK_TRY(rt_require());
-  hipStream_t s = G.s_main;
-  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
-  GPK_TRY(dev_alloc_t(&dA, (size_t)m * k));
-  GPK_TRY(dev_alloc_t(&dC, (size_t)m * n));
-  if (!lower) GPK_TRY(dev_alloc_t(&dB, (size_t)n * k));
-  // random-ish operands (DVFS: zero operands read high, guide rule 25)
-  std::vector<double> h((size_t)std::max(m, n) * k);
-  unsigned long long st = 88172645463325252ull;
-  for (auto& v : h) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = ((double)(st >> 11) / 9007199254740992.0 - 0.5) * 1e-3; }
-  GPK_HIP(hipMemcpyAsync(dA, h.data(), (size_t)m * k * 8, hipMemcpyHostToDevice, s));
-  if (!lower) GPK_HIP(hipMemcpyAsync(dB, h.data(), (size_t)n * k * 8, hipMemcpyHostToDevice, s));
-  GPK_TRY(launch_fill(dC, (size_t)m * n, 1.0, s));
-  GemmNT g{};
-  g.A = dA; g.lda = k; g.B = lower ? dA : dB; g.ldb = k; g.C = dC; g.ldc = n;
-  g.m = m; g.n = n; g.k = k; g.sub = 1; g.lower = lower & 1;
-  auto go = [&]() { return tile == 64 ? launch_gemm_nt(g, false, s) : launch_gemm_auto(g, s); };
-#ifdef GPK_GEMM_DBG_VARIANTS
-  // GPK_GEMM_TRACE=<file> with GPK_GEMM_DBG=32: per-workgroup stamps of ONE launch (after a warm-up launch) as raw u64[8] records
-  extern unsigned long long* g_gemm_trace;
-  if (getenv("GPK_GEMM_TRACE") && tile != 64) {
-    const size_t nw = (size_t)8 * 65536;
-    unsigned long long* dtr = nullptr;
-    GPK_HIP(hipMalloc((void**)&dtr, nw * 8));
-    GPK_HIP(hipMemset(dtr, 0, nw * 8));
-    (void)go();
-    GPK_HIP(hipStreamSynchronize(s));
-    g_gemm_trace = dtr;
-    (void)go();
-    GPK_HIP(hipStreamSynchronize(s));
-    g_gemm_trace = nullptr;
-    std::vector<unsigned long long> h(nw);
-    GPK_HIP(hipMemcpy(h.data(), dtr, nw * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dtr);
-    if (FILE* f = fopen(getenv("GPK_GEMM_TRACE"), "wb")) {
-      fwrite(h.data(), 8, nw, f);
-      fclose(f);
-    }
-  }
-#endif
-#ifdef GPK_GEMM_DBG_VARIANTS
-  // GPK_GEMM_TRACE=<file> with GPK_GEMM_DBG=32: per-workgroup stamps of ONE launch (after a warm-up launch) as raw u64[5] records
-  extern unsigned long long* g_gemm_trace;
-  if (getenv("GPK_GEMM_TRACE") && tile != 64) {
-    const size_t nw = (size_t)5 * 65536;
-    unsigned long long* dtr = nullptr;
-    GPK_HIP(hipMalloc((void**)&dtr, nw * 8));
-    GPK_HIP(hipMemset(dtr, 0, nw * 8));
-    (void)go();
-    GPK_HIP(hipStreamSynchronize(s));
-    g_gemm_trace = dtr;
-    (void)go();
-    GPK_HIP(hipStreamSynchronize(s));
-    g_gemm_trace = nullptr;
-    std::vector<unsigned long long> h(nw);
-    GPK_HIP(hipMemcpy(h.data(), dtr, nw * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dtr);
-    if (FILE* f = fopen(getenv("GPK_GEMM_TRACE"), "wb")) {
-      fwrite(h.data(), 8, nw, f);
-      fclose(f);
-    }
-  }
-#endif
-  int rc = go();
-  hipEvent_t e0, e1;
-  GPK_HIP(hipEventCreate(&e0));
-  GPK_HIP(hipEventCreate(&e1));
-  GPK_HIP(hipEventRecord(e0, s));
-  for (int r = 0; r < reps && !rc; ++r) rc = go();
-  GPK_HIP(hipEventRecord(e1, s));
-  GPK_HIP(hipEventSynchronize(e1));
-  float ms = 0;
-  GPK_HIP(hipEventElapsedTime(&ms, e0, e1));
-  if (ms_out) *ms_out = ms / reps;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  dev_free(dA, (size_t)m * k * 8);
-  dev_free(dC, (size_t)m * n * 8);
-  if (dB) dev_free(dB, (size_t)n * k * 8);
-  return rc;
 }
 
 }  // extern "C"

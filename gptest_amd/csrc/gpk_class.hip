@@ -5,7 +5,7 @@
 // on the same MFMA factorisation as regression; K itself is only ever multiplied.  Everything stays in HBM; per
 // iteration the host sees one scalar (max |f_new - f|, the stopping rule of the sibling loop GPpref.py:140).
 #include "../../include/gpk.h"
-#include "../../include/gpk_testhooks.h"
+#include "../../include/gpk_bench.h"
 #include "gpk_core.h"
 #include <cmath>
 

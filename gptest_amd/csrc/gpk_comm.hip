@@ -3,7 +3,6 @@
 // The reference has no distributed code at all; this is the exchange step that
 // BASELINE.json's north_star prescribes (panel broadcast over xGMI).
 #include "../../include/gpk.h"
-#include "../../include/gpk_testhooks.h"
 #include "gpk_core.h"
 #include <rccl/rccl.h>
 #include <cstring>
@@ -105,56 +104,6 @@ int gpk_comm_barrier(void) {
   return 0;
 }
 
-// Self-check of the RCCL calls this library makes, on a ONE-rank communicator (all a 1-GPU box can host): the same
-// datatypes, counts and stream pairing as the multi-rank path -- panel-sized ncclBroadcast on a high-priority
-// communication stream, ncclAllGather and ncclAllReduce(max) on the update stream -- with the payload checked afterwards.
-// It cannot prove anything about links between GPUs; it does prove the calls are accepted on these streams.
-int gpk_test_rccl_selfcheck(int n_doubles) {
-  GPK_TRY(rt_require());
-  if (G.nccl) return gpk_set_err(-1, "gpk_test_rccl_selfcheck: a communicator is already active");
-  if (n_doubles < 1) return gpk_set_err(-1, "gpk_test_rccl_selfcheck: n_doubles=%d", n_doubles);
-  ncclUniqueId id;
-  GPK_NCCL(ncclGetUniqueId(&id));
-  ncclComm_t c;
-  GPK_NCCL(ncclCommInitRank(&c, 1, id, 0));
-  double *a = nullptr, *b = nullptr;
-  int rc = 0;
-  const size_t n = (size_t)n_doubles;
-  hipStream_t sc = nullptr;
-  {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&sc, hipStreamNonBlocking, hi) != hipSuccess) {
-      (void)hipGetLastError();
-      ncclCommDestroy(c);
-      return gpk_set_err(-2, "gpk_test_rccl_selfcheck: no communication stream");
-    }
-  }
-  if (dev_alloc_t(&a, n) || dev_alloc_t(&b, n)) rc = -2;
-  std::vector<double> h(n), back(n);
-  for (size_t i = 0; i < n; ++i) h[i] = (double)(i % 1000) - 499.5;
-  do {
-    if (rc) break;
-    if (hipMemcpy(a, h.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = gpk_set_err(-2, "H2D failed"); break; }
-    // the broadcast on a high-priority stream of its own while the all-gather / all-reduce use the update stream: the
-    // stream pairing of the production path (potrf_group broadcasts on G.s_comm, fit_group / predict_group reduce on s_main)
-    ncclResult_t r = ncclBroadcast(a, a, n, ncclDouble, 0, c, sc);
-    if (r == ncclSuccess) r = ncclAllGather(a, b, n, ncclDouble, c, G.s_main);
-    if (r == ncclSuccess) r = ncclAllReduce(b, b, n, ncclDouble, ncclMax, c, G.s_main);
-    if (r != ncclSuccess) { rc = gpk_set_err(-3, "RCCL call failed: %s", ncclGetErrorString(r)); break; }
-    if (hipDeviceSynchronize() != hipSuccess) { rc = gpk_set_err(-2, "sync after RCCL calls failed: %s", hipGetErrorString(hipGetLastError())); break; }
-    if (hipMemcpy(back.data(), b, n * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
-    for (size_t i = 0; i < n; ++i)
-      if (back[i] != h[i]) { rc = gpk_set_err(-3, "payload mismatch at %zu", i); break; }
-  } while (0);
-  if (a) dev_free(a, n * 8);
-  if (b) dev_free(b, n * 8);
-  (void)hipDeviceSynchronize();
-  ncclCommDestroy(c);
-  (void)hipStreamDestroy(sc);
-  return rc;
-}
-
 int gpk_comm_destroy(void) {
   if (G.nccl) {
     (void)hipDeviceSynchronize();
@@ -163,6 +112,24 @@ int gpk_comm_destroy(void) {
   }
   G.rank = 0;
   G.nranks = 1;
+  // back to the single-GPU stream layout: the communication stream goes, the substitution stream a multi-rank process gave
+  // up for it (gpk_comm_init) comes back, so that a process that once joined a communicator runs the pipelined one-GPU
+  // path afterwards
+  if (G.inited) {
+    if (G.s_comm) {
+      (void)hipStreamSynchronize(G.s_comm);
+      (void)hipStreamDestroy(G.s_comm);
+      G.s_comm = nullptr;
+    }
+    if (!G.s_pred) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (hipStreamCreateWithPriority(&G.s_pred, hipStreamNonBlocking, hi) != hipSuccess) {
+        (void)hipGetLastError();
+        G.s_pred = nullptr;
+      }
+    }
+  }
   return 0;
 }
 

@@ -25,6 +25,8 @@ struct Runtime {
   hipStream_t s_main = nullptr, s_panel = nullptr;
   hipStream_t s_pred = nullptr;   // y and prediction substitutions pipelined behind the factorisation (fused fit+predict)
   hipStream_t s_comm = nullptr;   // multi-rank processes: the panel broadcasts (off the panel chain); virtual ranks use s_pred
+  hipStream_t s_corner = nullptr; // the deferred corner updates of the lazy-corner schedule (created on first use: corner_stream_ensure)
+  int s_corner_prio = -1;
   std::map<size_t, std::vector<void*>> pool;
   size_t pool_bytes = 0;
   // ---- options (gpk_set_option).  Panel schedule: nb = 0 is the automatic one -- 512-wide panels while more than
@@ -47,6 +49,22 @@ struct Runtime {
   int fuse_predict = 1;   // bench / compute_prediction: overlap the prediction solve with the factorisation tail
   int tail_tile_kernel = -1; // (-1: automatic, for Npad < 12288) tile pipeline: the two one-tile GEMMs of a step on the LDS-free 64-wave kernel instead of the 64x64-tile one
   int pred_defer_from = -1;  // (-1: automatic, 5/8 of the columns from Npad = 12288 on; 0: off) pipelined prediction: panels that end at or before this column update only the columns below it right away; their updates of the columns from it on are queued, in panel order, when the substitution reaches it (0: off)
+  // Lazy corner (potrf_device, one GPU, one-level schedule): with b the first panel boundary at or after corner_from, a panel that
+  // ends before b applies its trailing update right away only to the trapezoid of columns < b; the corner [b:, b:] receives the
+  // updates of those panels later, in panel order, as a few launches with K = corner_chunk columns (K-segment table of the 8-wave
+  // kernel) on a low-priority stream of its own -- filler for the chain-bound part of the factorisation, at the rate the kernel
+  // reaches at high K.  The last corner_last columns before b are applied together with the boundary panel's own update (so that
+  // what the chain waits for at b is short).  Bit-identical to the immediate schedule.  -1: automatic, 0: off.
+  int corner_from = 0, corner_chunk = 2048, corner_last = 256;
+  int corner_from2 = 0, corner_from3 = 0;  // further boundaries (nested regions): the columns from corner_from2 on are left out of the first region's
+                                           // catch-up and brought up to date when the chain reaches corner_from2 -- deferred work for the stretch between the two
+  int corner_grid = 256;  // workgroups of a catch-up launch (persistent form of the 8-wave kernel: they share the tiles through a counter); 0: one
+                          // workgroup per tile.  256 = one per CU: the other workgroup slot of every CU stays free for the panel chain
+  unsigned* dctr = nullptr;  // tile counters of the persistent launches (64, used round-robin)
+  unsigned dctr_next = 0;
+  int corner_prio = 0;  // priority of the corner stream: 0 lowest, 1 that of the update stream, 2 highest
+  int corner_hold = 0;  // no catch-up launch starts before the panel that begins at or after this column has been factored: the deferred work
+                        // is held back until the factorisation turns chain-bound instead of competing with the bulk-bound first part
   int small_tile_below = 256;  // panel_update: launches with fewer 128x128 tiles than this use the 64x64-tile kernel
   // launch graphs (fit_device, option graphs): the whole multi-stream enqueue of one fit (+ fused prediction) captured once
   // per (shape, buffers, schedule) and replayed afterwards -- the reference's caller evaluates one shape hundreds of times
@@ -188,6 +206,9 @@ extern int g_potrf_lookahead_used;  // 1 if the last potrf_device recorded per-p
 extern int g_dist_lookahead_used;   // 1 if the last block-cyclic factorisation ran the look-ahead schedule
 int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel = nullptr);                                 // dK -> dL, dDinv
 int model_events(gpk_model* m, int n);                         // at least n dependency events in m->ev
+int corner_stream_ensure();                                     // the corner stream exists (with the priority option corner_prio asks for)
+int corner_boundary(const gpk_model* m);                        // boundary column of the lazy-corner schedule for this model (0: off)
+extern int g_potrf_corner[3];                                   // boundaries the last factorisation deferred its far columns from (0: none)
 // Block-cyclic (P > 1) entry points work on the LOCAL rank models of one job: a real rank passes itself (n = 1,
 // peers are other processes, exchange = RCCL), the single-process test harness passes all P virtual ranks
 // (exchange = device copies).  Same schedule, same code.
@@ -211,3 +232,5 @@ int rows_backward_solve(gpk_model* m, int Mpad, double* dR, double* dY, const do
 int trsv_forward(gpk_model* m, double* v);                      // v <- L^-1 v  (Npad vector)
 int trsv_backward(gpk_model* m, double* v);                     // v <- L^-T v
 int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, double* dV, double* dmean, double* dvar);
+int model_unpack_L(gpk_model* m, double* L_out_host);                                 // the packed factor as a dense N x N lower matrix on the host
+int launch_pad_identity(double* K, long ld, int N, int Npad, hipStream_t s);          // identity in the padding rows / columns of a caller matrix

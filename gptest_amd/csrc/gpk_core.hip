@@ -399,7 +399,7 @@ static int pair_update(gpk_model* m, int p, int r0g, hipStream_t s) {
   const int np_ = m->Npad, rows = np_ - r0g;
   if (rows <= 0) return 0;
   const long nt = rows / 128;
-  if (nt * (nt + 1) / 2 < G.small_tile_below || m->pld[p] != m->pld[p + 1]) {  // the kernel wants equal leading dimensions
+  if (nt * (nt + 1) / 2 < G.small_tile_below) {
     GPK_TRY(panel_update(m, p, r0g, r0g, rows, 1, s));
     return panel_update(m, p + 1, r0g, r0g, rows, 1, s);
   }
@@ -590,6 +590,118 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
   return 0;
 }
 
+// ------------------------------------------------------------------ lazy corner (see Runtime::corner_from)
+int g_potrf_corner[3] = {0, 0, 0};
+int corner_stream_ensure() {
+#ifndef GPK_HOSTSIM
+  if (G.s_corner && G.s_corner_prio == G.corner_prio) return 0;
+  if (G.s_corner) {
+    GPK_HIP(hipStreamSynchronize(G.s_corner));
+    GPK_HIP(hipStreamDestroy(G.s_corner));
+    G.s_corner = nullptr;
+  }
+  int lo = 0, hi = 0;
+  GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  const int pr = G.corner_prio >= 2 ? hi : (G.corner_prio == 1 ? (lo + hi) / 2 : lo);
+  GPK_HIP(hipStreamCreateWithPriority(&G.s_corner, hipStreamNonBlocking, pr));
+  G.s_corner_prio = G.corner_prio;
+#else
+  if (!G.s_corner) GPK_HIP(hipStreamCreateWithPriority(&G.s_corner, hipStreamNonBlocking, 0));
+#endif
+  return 0;
+}
+static int tail_first_panel(const gpk_model* m);
+// The boundaries (options corner_from, corner_from2, corner_from3; increasing): panel starts, the first with at least two panels in
+// front of it, none beyond the start of the tile-pipeline tail, at least two tile columns behind each.  One-level schedules on
+// one GPU only (with two-level blocking the outer updates already run at K = nb_outer).  out3: the boundaries found (0-filled).
+int corner_boundaries(const gpk_model* m, int* out3) {
+  out3[0] = out3[1] = out3[2] = 0;
+  const int wants[3] = {G.corner_from < 0 ? 0 : G.corner_from, G.corner_from2, G.corner_from3};  // (automatic: off until DESIGN.md section 6 says otherwise)
+  if (wants[0] <= 0 || m->P != 1 || m->growable || !G.lookahead || m->nO != m->nP || m->nP < 4) return 0;
+  const int o_tail = tail_first_panel(m);
+  const int cmax = (o_tail < m->nO) ? m->oc0[o_tail] : m->Npad - 256;
+  int n = 0, o = 2;
+  for (int i = 0; i < 3 && wants[i] > 0; ++i) {
+    while (o < m->nO && m->oc0[o] < wants[i]) ++o;
+    if (o >= m->nO || m->oc0[o] > cmax || m->Npad - m->oc0[o] < 256) break;
+    out3[n++] = m->oc0[o];
+    ++o;  // the next boundary is a later panel start
+  }
+  return n;
+}
+int corner_boundary(const gpk_model* m) {
+  int b[3];
+  corner_boundaries(m, b);
+  return b[0];
+}
+// Region i of the lazy schedule: columns [b, bend) x rows >= b (a lower trapezoid).  It receives the updates of the panels in front
+// of b from catch-up launches on the corner stream (chunks of panels, in order; none before panel hold_panel has been factored),
+// the last few of them -- panels [final_first, q) -- together with the update of the boundary panel q - 1.
+struct CornerRegion {
+  int b = 0, bend = 0, q = 0;
+  int final_first = 0;
+  std::vector<int> chunk_end;   // chunk j = panels [chunk_end[j-1], chunk_end[j]), chunk_end.back() == final_first
+  int hold_panel = 0;
+  size_t next_chunk = 0;
+  hipEvent_t ev_last = nullptr;  // the last catch-up launch queued so far
+  int ev_base = 0;               // this region's first event in m->ev
+};
+static std::vector<CornerRegion> corner_plan(const gpk_model* m) {
+  std::vector<CornerRegion> R;
+  int bs[3];
+  const int n = corner_boundaries(m, bs);
+  const int chunk = std::max(G.corner_chunk, 128);
+  for (int i = 0; i < n; ++i) {
+    CornerRegion r;
+    r.b = bs[i];
+    r.bend = (i + 1 < n) ? bs[i + 1] : m->Npad;
+    while (m->pc0[r.q] < r.b) ++r.q;
+    int f = r.q - 1;
+    while (f > 0 && r.b - m->pc0[f - 1] <= std::max(G.corner_last, m->pw[r.q - 1]) && r.q - (f - 1) <= GPK_MAXSEG) --f;
+    r.final_first = f;
+    int k = 0, cnt = 0;
+    for (int p = 0; p < f; ++p) {
+      k += m->pw[p];
+      ++cnt;
+      if (k >= chunk || cnt == GPK_MAXSEG || p == f - 1) {
+        r.chunk_end.push_back(p + 1);
+        k = cnt = 0;
+      }
+    }
+    // the first region's catch-up is held back until the chain reaches column corner_hold; a later region's until the chain
+    // reaches the boundary in front of it (its deferred work fills the chain-bound stretch between the two boundaries)
+    const int hold_col = (i == 0) ? G.corner_hold : bs[i - 1];
+    while (r.hold_panel + 1 < f && m->pc0[r.hold_panel] < hold_col) ++r.hold_panel;
+    if (f > 0) r.hold_panel = std::min(r.hold_panel, f - 1);
+    r.ev_base = (7 + i) * m->nP + 8;
+    R.push_back(r);
+  }
+  return R;
+}
+// C[r0g:, c0g : c0g + ncols] -= sum over outer panels o in [o_first, o_last] of Lo[(r0g - oc0):, :] Lo[(c0g - oc0) : +ncols, :]^T, in
+// panel order, as ONE launch of the 8-wave kernel over a K-segment table (one panel: the plain update, any tile size)
+static int span_update(gpk_model* m, int o_first, int o_last, int r0g, int c0g, int ncols, int lower, hipStream_t s, int persist_grid = 0) {
+  if (o_first == o_last && persist_grid <= 0) return outer_update(m, o_last, r0g, c0g, ncols, lower, s);
+  const int rows = m->Npad - r0g;
+  if (rows <= 0 || ncols <= 0) return 0;
+  if (o_last - o_first + 1 > GPK_MAXSEG) return gpk_set_err(-1, "internal: %d panels in one update", o_last - o_first + 1);
+  GemmSegs sg{};
+  for (int o = o_first; o <= o_last; ++o) {
+    const int W = m->ow[o];
+    GemmSeg& q = sg.s[sg.n++];
+    q.A = m->Lo(o) + (long)(r0g - m->oc0[o]) * W;
+    q.B = m->Lo(o) + (long)(c0g - m->oc0[o]) * W;
+    q.lda = q.ldb = W;
+    q.k = W;
+  }
+  GemmNT g{};
+  g.C = m->dK + (long)r0g * m->ldk + c0g; g.ldc = m->ldk;
+  g.m = rows; g.n = ncols; g.sub = 1; g.lower = lower;
+  unsigned* ctr = nullptr;
+  if (persist_grid > 0 && G.dctr) ctr = G.dctr + (G.dctr_next++ & 63);
+  return launch_gemm_nt_segs(g, sg, s, ctr ? persist_grid : 0, ctr);
+}
+
 // first outer panel of the tile-pipeline tail (nO: no tail): from there on every panel is a single 128-wide one
 static int tail_first_panel(const gpk_model* m) {
   if (!G.tail_rows || m->P != 1) return m->nO;
@@ -629,9 +741,10 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   // run faster (50 vs 44.5 TFLOP/s) but the three narrow updates per pair it needs (16 % of the flops) cost more
   // than that (N = 16384: 38.1-38.5 vs 36.9-37.05 ms, N = 32768: 241.8 vs 231.9).  1: only up to 8192, 2: always.
   g_potrf_tail_from = -1;
+  g_potrf_corner[0] = g_potrf_corner[1] = g_potrf_corner[2] = 0;
   if (nP >= 6 && m->nO == nP && tail_first_panel(m) == m->nO && (G.pair_update == 2 || (G.pair_update == 1 && m->Npad <= 8192)))
     return potrf_device_paired(m, after_panel);
-  GPK_TRY(model_events(m, 7 * nP + 8));
+  GPK_TRY(model_events(m, 10 * nP + 8));
   g_potrf_lookahead_used = 1;
   hipEvent_t* ev_panel = m->ev.data();        // inner panel p factored (recorded on s_panel)
   hipEvent_t* ev_trail = m->ev.data() + nP;   // rest-update of OUTER step o done (recorded on s_main)
@@ -663,23 +776,63 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   const int o_tail = tail_first_panel(m);  // outer panels from here on go through the tile pipeline
   g_potrf_tail_from = (o_tail < nO) ? m->ofirst[o_tail] : -1;
   if (o_tail == 0) return potrf_tail(m, 0, ev_start, after_panel);
+  // Lazy corner (Runtime::corner_from): a panel in front of a boundary b updates columns < b only; the region behind the boundary
+  // gets the updates of all panels in front of it from catch-up launches on the corner stream (chunks of panels, in order), the
+  // last few of them together with the update of the boundary panel, the first one that needs the region up to date.  Up to
+  // three nested regions.  Every element still receives the same rank-w updates in the same order inside fp64 MFMA chains that
+  // start from the stored value: the same bits.
+  std::vector<CornerRegion> regs = corner_plan(m);
+  for (int i = 0; i < 3; ++i) g_potrf_corner[i] = (i < (int)regs.size()) ? regs[i].b : 0;
+  if (!regs.empty()) GPK_TRY(corner_stream_ensure());
   GPK_TRY(factor_outer(0, sp, nullptr));
   for (int o = 0; o < nO; ++o) {
     const int r0 = m->oc0[o] + m->ow[o];             // first row/col of the trailing matrix
+    CornerRegion* bd = nullptr;                       // the region this panel's update brings up to date (it ends at that boundary)
+    int ccap = np_;                                   // columns this panel's update may touch now: [.., ccap)
+    for (auto& rg : regs) {
+      if (o == rg.q - 1) { bd = &rg; ccap = rg.bend; break; }
+      if (r0 < rg.b) { ccap = rg.b; break; }
+    }
+    const int pf = bd ? bd->final_first : o;         // the panels this step applies: [pf, o]
+    hipEvent_t ev_bd = bd ? bd->ev_last : nullptr;    // (assigned below, after this step's catch-up launches are queued)
+    int kspan = 0;
+    for (int q = pf; q <= o; ++q) kspan += m->ow[q];
+    // catch-up launches that are due: a chunk's panels are all factored (the last of them in the previous step) and the chain
+    // has reached the region's hold column
+    for (auto& rg : regs)
+      while (rg.next_chunk < rg.chunk_end.size() && std::max(rg.chunk_end[rg.next_chunk] - 1, rg.hold_panel) <= o) {
+        const int first = rg.next_chunk ? rg.chunk_end[rg.next_chunk - 1] : 0, last = rg.chunk_end[rg.next_chunk] - 1;
+        hipStream_t sc = G.s_corner;
+        GPK_HIP(hipStreamWaitEvent(sc, ev_panel[m->oend[std::max(last, rg.hold_panel)] - 1], 0));
+        int kc = 0;
+        for (int q = first; q <= last; ++q) kc += m->ow[q];
+        const double mm = (double)(np_ - rg.b), below = (double)(np_ - rg.bend);
+        timer_begin("trailing", sc, (mm * mm - below * below) * kc);
+        GPK_TRY(span_update(m, first, last, rg.b, rg.b, rg.bend - rg.b, 1, sc, G.corner_grid));
+        timer_end("trailing", sc);
+        hipEvent_t e = m->ev[rg.ev_base + rg.next_chunk];
+        GPK_HIP(hipEventRecord(e, sc));
+        if (G.stamps && G.dstamps && &rg == &regs[0] && rg.next_chunk < 64) GPK_TRY(launch_stamp(G.dstamps + 448 + rg.next_chunk, sc));
+        rg.ev_last = e;
+        ++rg.next_chunk;
+      }
+    ev_bd = bd ? bd->ev_last : nullptr;
     if (o_tail < nO && o + 1 == o_tail) {
       // hand-over to the tile pipeline: its first leaf needs tile column o+1, its first T / LAnear the two columns
       // after it, so the chain stream applies this panel to three tile columns, the update stream to the rest
       // (which then stands for REST(first tail panel - 1))
       const int w_la = std::min(384, np_ - r0);
       if (o > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[o - 1], 0));
-      GPK_TRY(outer_update(m, o, r0, r0, w_la, 1, sp));
+      if (ev_bd) GPK_HIP(hipStreamWaitEvent(sp, ev_bd, 0));
+      GPK_TRY(span_update(m, pf, o, r0, r0, w_la, 1, sp));
       GPK_HIP(hipStreamWaitEvent(sm, ev_panel[m->oend[o] - 1], 0));
+      if (ev_bd) GPK_HIP(hipStreamWaitEvent(sm, ev_bd, 0));
       const int r1 = r0 + w_la;
       if (np_ - r1 > 0) {
         const long nt = (np_ - r1) / 128;
         const char* tname = (nt * (nt + 1) / 2 < G.small_tile_below) ? "trailing_small" : "trailing";
-        timer_begin(tname, sm, (double)(np_ - r1) * (np_ - r1) * m->ow[o]);
-        GPK_TRY(outer_update(m, o, r1, r1, np_ - r1, 1, sm));
+        timer_begin(tname, sm, (double)(np_ - r1) * (np_ - r1) * kspan);
+        GPK_TRY(span_update(m, pf, o, r1, r1, np_ - r1, 1, sm));
         timer_end(tname, sm);
       }
       GPK_HIP(hipEventRecord(ev_trail[o], sm));
@@ -690,14 +843,16 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
     if (o + 1 < nO) {
       // (a) s_panel: the look-ahead column gets outer panel o's update (lower trapezoid) ...
       if (o > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[o - 1], 0));  // earlier updates of that column
-      GPK_TRY(outer_update(m, o, r0, r0, w1, 1, sp));
+      if (ev_bd) GPK_HIP(hipStreamWaitEvent(sp, ev_bd, 0));  // ... those of the region's catch-up launches
+      GPK_TRY(span_update(m, pf, o, r0, r0, w1, 1, sp));
     }
     GPK_HIP(hipStreamWaitEvent(sm, ev_panel[m->oend[o] - 1], 0));
+    if (ev_bd) GPK_HIP(hipStreamWaitEvent(sm, ev_bd, 0));
     const long ntr = (np_ - r0 - w1) / 128;
     const char* tname = (ntr * (ntr + 1) / 2 < G.small_tile_below) ? "trailing_small" : "trailing";
     if (wn - w1 > 0) {
       // (b1) s_main: the other columns of block column o+1 first, so that the inner updates of its factorisation
-      // can follow the first inner panel without waiting for the whole trailing update
+      // can follow the first inner panel without waiting for the whole trailing update  (two-level schedules: no lazy corner)
       timer_begin(tname, sm, (double)(wn - w1) * (2.0 * (np_ - r0 - w1) - (wn - w1)) * m->ow[o]);
       GPK_TRY(outer_update(m, o, r0 + w1, r0 + w1, wn - w1, 1, sm));
       timer_end(tname, sm);
@@ -705,13 +860,14 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
     }
     //     ... and block column o+1 is factored on s_panel.
     if (o + 1 < nO) GPK_TRY(factor_outer(o + 1, sp, (wn - w1 > 0) ? ev_blk[o] : nullptr));
-    // (b2) s_main: the rest of the trailing matrix (lower triangle starting after block column o+1)
+    // (b2) s_main: the rest of the trailing matrix (lower triangle starting after block column o+1; lazy: its columns below b)
     const int r1 = r0 + wn;
-    if (np_ - r1 > 0) {
+    if (ccap - r1 > 0) {
       // "trailing" = the launches of the 8-wave kernel (the roofline object of bench.py); the latency-bound
       // tail that outer_update routes to the 64x64-tile kernel is timed under its own name
-      timer_begin(tname, sm, (double)(np_ - r1) * (np_ - r1) * m->ow[o]);
-      GPK_TRY(outer_update(m, o, r1, r1, np_ - r1, 1, sm));
+      const double mm = (double)(np_ - r1), below = (double)(np_ - ccap);
+      timer_begin(tname, sm, (mm * mm - below * below) * kspan);
+      GPK_TRY(span_update(m, pf, o, r1, r1, ccap - r1, 1, sm));
       timer_end(tname, sm);
     }
     GPK_HIP(hipEventRecord(ev_trail[o], sm));
@@ -1150,11 +1306,12 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     }
     m->hpin_doubles = need;
   }
-  if (G.stamps && !G.dstamps && m->nP <= 512) {
+  if (G.stamps && !G.dstamps && m->nP <= 448) {
     GPK_HIP(hipMalloc((void**)&G.dstamps, 1024 * 8));
     G.hstamps.assign(1024, 0);
   }
-  GPK_TRY(model_events(m, 7 * m->nP + 8));
+  GPK_TRY(model_events(m, 10 * m->nP + 8));
+  if (corner_boundary(m)) GPK_TRY(corner_stream_ensure());  // (before a capture starts)
   m->hpin[2] = 0.0;
   int rc = 0;
   bool done = false;

@@ -8,7 +8,7 @@
 // i.e. O((128 + k) n^2) flops instead of n^3/3, with the factor of the first t0 columns left where it is.
 // Needs a model fitted with flag 4 ("growable": uniform 128-wide panels, a layout that does not depend on N).
 #include "../../include/gpk.h"
-#include "../../include/gpk_testhooks.h"
+#include "../../include/gpk_bench.h"
 #include "gpk_core.h"
 #include <cmath>
 

@@ -65,8 +65,28 @@ struct GemmNT {
   int prio;  // 64x64-tile kernel: raise the waves' issue priority (s_setprio): set by launch_gemm_nt for launches on the panel-chain stream
   unsigned long long* trace;  // timing builds only (make DBG=1): per-workgroup time stamps
 };
+// K-segment table of the 8-wave kernel: the K range of ONE update is the concatenation of up to GPK_MAXSEG separately stored
+// operand pairs (factored panels, each packed with its own leading dimension), applied in table order inside one MFMA chain
+// per output element -- bit for bit the result of one launch per segment in that order, with one C load / store instead
+// of one per segment (the deferred corner update of the factorisation, potrf_device; the paired trailing update).
+#define GPK_MAXSEG 32
+struct GemmSeg {
+  const double* A;  // rows of C tile row 0 (the kernel adds ti * 128 * lda)
+  const double* B;  // rows of C tile column 0
+  int lda, ldb;
+  int k;            // columns of this segment (multiple of 16)
+  int pad_;
+};
+struct GemmSegs {
+  int n;
+  int pad_;
+  GemmSeg s[GPK_MAXSEG];
+};
 // tile128 = true: the 8-wave 128x128-tile kernel (LDS-DMA staged); false: the 64x64-tile kernel (4 waves, 2x2 MFMA tiles each).
 int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s);
+// the 8-wave kernel over a K-segment table: g.A / g.B / g.k / g.k1 are ignored (k = sum of the segments), single GPU only
+// persist_grid > 0 (and a device counter): the persistent form -- that many workgroups share the tiles through the counter
+int launch_gemm_nt_segs(const GemmNT& g, const GemmSegs& segs, hipStream_t s, int persist_grid = 0, unsigned* counter = nullptr);
 // one 128 x 128 x 128 product on 64 waves without LDS (the chain's one-tile GEMMs); bitwise the other kernels
 int launch_gemm_tile128(const GemmNT& g, hipStream_t s);
 // the 8-wave kernel, with the XCD-aware tile order for the largest updates

@@ -2,7 +2,7 @@
 // on top of a fitted model handle (K + eps*I factored, unfactored copy kept).  Everything stays in HBM;
 // per Newton iteration the host sees one scalar (max |f_new - f|).
 #include "../../include/gpk.h"
-#include "../../include/gpk_testhooks.h"
+#include "../../include/gpk_bench.h"
 #include "gpk_core.h"
 #include <cmath>
 

@@ -268,16 +268,20 @@ static __device__ __forceinline__ void glds16(const double* sbase, unsigned voff
                : "memory");
 }
 
-// TWOSEG: the K range continues in (A2, B2) after k1 columns (paired trailing update).  NEG = (sub != 0).
+// SEG: the K range is the concatenation of the operand pairs of a K-segment table (gpk_internal.h: GemmSegs), each with its
+// own leading dimensions -- the slab DMA walks the table with a cursor of scalar registers (base pointers, slabs left) and
+// two per-lane offsets that are recomputed at a segment boundary only; the MFMA loop reads LDS and never sees the
+// segments, so the result is bit for bit that of one launch per segment in table order.  NEG = (sub != 0).
 // DBG (make DBG=1, timing only, wrong results): 1 no DMA in the loop, 2 no barriers, 4 no C load, 128 no C store, 8 neither, 16 every
 // tile reads tile 0's first slab, 64 every workgroup uses one of 8 C tiles, 256 first-round workgroups start spread over a tile time;
 // 32 (right results) per-workgroup time stamps into g.trace, +512 shader cycles of the main loop in place of the set-up stamp.  (A raised wave priority for the prologue and the store tail -- s_setprio 3 -- shortens the prologue by 2 us and lengthens the neighbour's slab loop by as much: profiles/r03_gemm_tile_trace.txt.)
-template <bool TWOSEG, bool NEG, int DBG = 0>
-__global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
+struct NoSegs {};
+template <bool SEG> struct SegArg { typedef NoSegs type; };
+template <> struct SegArg<true> { typedef GemmSegs type; };
+// one 128x128 tile (tile number `bid` of the launch) by the 512 threads of a workgroup; lds: 2 * 2 * 128 * BK doubles
+template <bool SEG, bool NEG, int DBG>
+static __device__ __forceinline__ void gemm_nt8_tile(const GemmNT& g, const typename SegArg<SEG>::type& segs, double* lds, const unsigned bid) {
   constexpr int BT = 128;
-  // the unpadded LDS image, exactly 64 KiB: two workgroups per CU leave 32 KiB, and ONE finished workgroup frees a 96 KiB
-  // slot, which is what the slot-sized leaf (k_potf2.hip) is built to fit
-  __shared__ double lds[2 * 2 * BT * BK];
   unsigned long long st_entry = 0, st_first = 0, st_last = 0, st_a = 0, st_b = 0, st_c = 0;
   if (DBG & 32) st_entry = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x, lane = tid & 63;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     // 8x8-tile squares; the 64 consecutive blocks of one XCD take one square, so the tiles an XCD works on
     // share 8 A and 8 B row-blocks (4 MiB at k = 256: its L2) instead of streaming a new B block per tile.
     const int ntm = g.m / BT;
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int xcd = bid & 7, seq = bid >> 3;
     const int sq = (seq >> 6) * 8 + xcd, slot = seq & 63;
     const int SN = (ntn + 7) >> 3;
     int I, J;
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     tj = J * 8 + (slot & 7);
     if (ti >= ntm || tj >= ntn || (g.lower && tj > ti)) return;
   } else if (g.lower && g.cyc_P == 0) {
-    int id = blockIdx.x;
+    int id = bid;
     const int tri = ntn * (ntn + 1) / 2;
     if (id < tri) {
       int t = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
@@ -329,8 +333,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
       tj = id % ntn;
     }
   } else {
-    ti = blockIdx.x / ntn;
-    tj = blockIdx.x % ntn;
+    ti = bid / ntn;
+    tj = bid % ntn;
   }
   long brow0;
   if (g.cyc_P > 0) {
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   const double* Ag = (DBG & 16) ? g.A : g.A + (long)ti * BT * g.lda;  // DBG 16: every tile reads tile 0's first slab (cache hits)
   const double* Bg = (DBG & 16) ? g.B : g.B + brow0 * g.ldb;
   const int fr = lane & 15, fg = lane >> 4;
-  double* Cw = (DBG & 64) ? g.C + ((long)(blockIdx.x & 7) * BT + wm * 64) * g.ldc + wn * 32  // DBG 64: every workgroup uses one of 8 C tiles (cache hits)
+  double* Cw = (DBG & 64) ? g.C + ((long)(bid & 7) * BT + wm * 64) * g.ldc + wn * 32  // DBG 64: every workgroup uses one of 8 C tiles (cache hits)
                           : g.C + ((long)ti * BT + wm * 64) * g.ldc + (long)tj * BT + wn * 32;  // wave-uniform
   const unsigned c_off = (unsigned)fg * (unsigned)g.ldc + (unsigned)fr;
 
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     }
   };
 
-  const int nk = g.k / BK;
+  const int nk = g.k / BK;  // (SEG: the host sets g.k to the sum of the segments)
   // Staging by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no negation pass (the MFMA
   // negates A: BLGP bit 0 of the f64 MFMAs).  The LDS image is lane-linear per wave-instruction -- 8 rows of 128 bytes
   // -- so rows are unpadded and the bank conflicts are swizzled away on the SOURCE side: LDS (row r, 16-byte chunk c)
@@ -379,22 +383,40 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   const unsigned lds0 = (unsigned)(unsigned long)(lds_double*)lds;
   const int rr = wid * 8 + (lane >> 3);  // the row this lane fills (and rr + 64)
   const int gch = ((lane & 7) ^ ((rr >> 1) & 7)) * 2;
-  const unsigned voA = (unsigned)(((long)rr * g.lda + gch) * 8);  // < 4 GiB: 128 rows of one operand (host check)
-  const unsigned voB = (unsigned)(((long)rr * g.ldb + gch) * 8);
-  const long a64 = 64 * g.lda, b64 = 64 * g.ldb;
-  const int nk1g = TWOSEG ? g.k1 / BK : 0;
-  const double* Ag2g = TWOSEG ? g.A2 + (long)ti * BT * g.lda2 : Ag;  // second K segment: same leading dimensions (host check)
-  const double* Bg2g = TWOSEG ? g.B2 + brow0 * g.ldb2 : Bg;
-  auto dma = [&](int kt, int buf) {
-    if (DBG & 16) kt = 0;
+  // DMA cursor: slabs are requested strictly in order, so the source is a pair of scalar pointers that advance by one slab
+  // per request; with a segment table they are reloaded (with the leading dimensions and the per-lane offsets that depend
+  // on them) when a segment runs out -- a scalar branch taken once per segment, not per slab.
+  const double *cAp = Ag, *cBp = Bg;
+  unsigned voA = (unsigned)(((long)rr * g.lda + gch) * 8);  // < 4 GiB: 128 rows of one operand (host check)
+  unsigned voB = (unsigned)(((long)rr * g.ldb + gch) * 8);
+  long a64 = 64 * g.lda, b64 = 64 * g.ldb;
+  int seg_i = 0, seg_left = nk;
+  auto seg_open = [&](int i) {
+    if constexpr (SEG) {
+      const GemmSeg& sg = segs.s[i];
+      cAp = sg.A + (long)ti * BT * sg.lda;
+      cBp = sg.B + brow0 * sg.ldb;
+      voA = (unsigned)(((long)rr * sg.lda + gch) * 8);
+      voB = (unsigned)(((long)rr * sg.ldb + gch) * 8);
+      a64 = 64 * (long)sg.lda;
+      b64 = 64 * (long)sg.ldb;
+      seg_left = sg.k / BK;
+    }
+  };
+  if constexpr (SEG) seg_open(0);
+  auto dma = [&](int buf) {
     const unsigned dst = lds0 + (unsigned)((buf * STG + wid * 8 * BK) * 8);
-    const bool first = !TWOSEG || kt < nk1g;  // scalar select of the segment: slabs [0, nk1) from (A, B), the rest from (A2, B2)
-    const double* Ap = (first ? Ag : Ag2g) + (first ? kt : kt - nk1g) * BK;
-    const double* Bp = (first ? Bg : Bg2g) + (first ? kt : kt - nk1g) * BK;
-    glds16(Ap, voA, dst);
-    glds16(Ap + a64, voA, dst + 64 * BK * 8);
-    glds16(Bp, voB, dst + OPD * 8);
-    glds16(Bp + b64, voB, dst + OPD * 8 + 64 * BK * 8);
+    glds16(cAp, voA, dst);
+    glds16(cAp + a64, voA, dst + 64 * BK * 8);
+    glds16(cBp, voB, dst + OPD * 8);
+    glds16(cBp + b64, voB, dst + OPD * 8 + 64 * BK * 8);
+    if (!(DBG & 16)) {  // DBG 16: every request reads the first slab
+      cAp += BK;
+      cBp += BK;
+    }
+    if constexpr (SEG) {
+      if (--seg_left == 0 && ++seg_i < segs.n) seg_open(seg_i);
+    }
   };
   const int fsw = (fr >> 1) & 7;
   int koff[4];
@@ -443,14 +465,14 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
   // guest poll (gpk_internal.h): wave 0 only; the value read during one slab is looked at after the next barrier
   const unsigned* gslot = (wid == 0 && g.guest) ? g.guest + cu_guest_slot() : nullptr;
   unsigned gv = 0;
-  if ((DBG & 256) && blockIdx.x < 512) {  // DBG 256: first-round workgroups start spread over one tile time (is the C hand-over a chip-wide convoy?)
+  if ((DBG & 256) && bid < 512) {  // DBG 256: first-round workgroups start spread over one tile time (is the C hand-over a chip-wide convoy?)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long dl = (unsigned long long)(((blockIdx.x * 2654435761u) >> 29) & 7u) * (unsigned long long)g.k * 3ull;  // x/8 of 0.234 us * k, in 10 ns ticks
+    const unsigned long long dl = (unsigned long long)(((bid * 2654435761u) >> 29) & 7u) * (unsigned long long)g.k * 3ull;  // x/8 of 0.234 us * k, in 10 ns ticks
     while (__builtin_amdgcn_s_memrealtime() - t0 < dl) __builtin_amdgcn_s_sleep(8);
   }
   if (DBG & 32) st_a = __builtin_amdgcn_s_memrealtime();
-  dma(0, 0);
-  if (nk > 1) dma(1, 1);
+  dma(0);
+  if (nk > 1) dma(1);
   init_acc();  // (the first two slabs are requested BEFORE the C tile, which queues behind them in the load path)
   if (DBG & 32) st_b = __builtin_amdgcn_s_memrealtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -487,7 +509,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
     __builtin_amdgcn_sched_barrier(0);
     mm(1);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DBG & 1) && kt + 2 < nk) dma(kt + 2, buf);
+    if (!(DBG & 1) && kt + 2 < nk) dma(buf);
     if (gslot) {  // scalar branch: wave 0
       if (__builtin_amdgcn_readfirstlane((int)gv) != 0) {
         // a guest (the leaf) is on this CU: stay out of its way.  The other seven waves stop at the next barrier.
@@ -512,7 +534,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
         for (int r = 0; r < 4; ++r) t += acc[i][j][r];
     if (t == 12345.678) Cw[c_off] = t;
     if ((DBG & 32) && g.trace && tid == 0) {
-      unsigned long long* tr = g.trace + 8 * (size_t)blockIdx.x;
+      unsigned long long* tr = g.trace + 8 * (size_t)bid;
       tr[0] = st_entry; tr[1] = st_first; tr[2] = st_last; tr[3] = __builtin_amdgcn_s_memrealtime(); tr[4] = cu_guest_slot();
       tr[5] = st_a; tr[6] = st_b; tr[7] = st_c;
     }
@@ -530,9 +552,37 @@ __global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g) {
         __hip_atomic_store((Cw + (long)(i * 16 + 4 * r) * g.ldc + j * 16) + c_off, acc[i][j][r], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
   if ((DBG & 32) && g.trace && tid == 0) {
-    unsigned long long* t = g.trace + 8 * (size_t)blockIdx.x;
+    unsigned long long* t = g.trace + 8 * (size_t)bid;
     t[0] = st_entry; t[1] = st_first; t[2] = st_last; t[3] = __builtin_amdgcn_s_memrealtime(); t[4] = cu_guest_slot();
     t[5] = st_a; t[6] = st_b; t[7] = st_c;
+  }
+}
+
+
+template <bool SEG, bool NEG, int DBG = 0>
+__global__ __launch_bounds__(512, 4) void gemm_nt8_kernel(GemmNT g, typename SegArg<SEG>::type segs) {
+  // the unpadded LDS image, exactly 64 KiB: two workgroups per CU leave 32 KiB, and ONE finished workgroup frees a 96 KiB
+  // slot, which is what the slot-sized leaf (k_potf2.hip) is built to fit
+  __shared__ double lds[2 * 2 * 128 * BK];
+  gemm_nt8_tile<SEG, NEG, DBG>(g, segs, lds, blockIdx.x);
+}
+
+// Persistent form for the deferred corner updates (K in the thousands, a tile takes half a millisecond): a grid SMALLER than
+// the chip's 512 workgroup slots -- by default one workgroup per CU -- whose workgroups take tiles from a counter until
+// none is left.  The slots it does not take stay free for the whole launch: the panel chain's kernels (and the short
+// K = 256 updates of the update stream) find one at once instead of waiting for a half-millisecond tile to retire, which is
+// what made the chain 30 % slower beside a plain grid of such tiles.  Same tile code, same bits.
+template <bool NEG>
+__global__ __launch_bounds__(512, 4) void gemm_nt8_persistent_kernel(GemmNT g, GemmSegs segs, unsigned* counter, unsigned ntiles) {
+  __shared__ double lds[2 * 2 * 128 * BK];
+  __shared__ unsigned next_tile;
+  for (;;) {
+    if (threadIdx.x == 0) next_tile = atomicAdd(counter, 1u);
+    __syncthreads();  // (also: every wave has left the previous tile's last LDS reads behind)
+    const unsigned t = next_tile;
+    __syncthreads();
+    if (t >= ntiles) return;
+    gemm_nt8_tile<true, NEG, 0>(g, segs, lds, t);
   }
 }
 
@@ -545,10 +595,14 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
     return gpk_set_err(-1, "gemm_nt: operands must be 16-byte aligned with even leading dimensions");
   if (g.lda >= (1l << 22) || g.ldb >= (1l << 22))  // LDS-DMA staging: 128 rows of an operand within a 32-bit byte offset
     return gpk_set_err(-1, "gemm_nt: leading dimensions must stay below 2^22");
-  if (g.k1 > 0) {
+  if (g.k1 > 0) {  // two separately stored operands: a table of two segments
     if (!tile128 || g.cyc_P != 0) return gpk_set_err(-1, "gemm_nt: a second K segment needs the 8-wave single-GPU kernel");
-    if (g.k1 % BK || g.k1 >= g.k || !g.A2 || !g.B2 || g.lda2 != g.lda || g.ldb2 != g.ldb || ((uintptr_t)g.A2 & 15) || ((uintptr_t)g.B2 & 15))
-      return gpk_set_err(-1, "gemm_nt: bad second K segment (k1=%d k=%d)", g.k1, g.k);
+    if (g.k1 >= g.k || !g.A2 || !g.B2) return gpk_set_err(-1, "gemm_nt: bad second K segment (k1=%d k=%d)", g.k1, g.k);
+    GemmSegs sg{};
+    sg.n = 2;
+    sg.s[0] = GemmSeg{g.A, g.B, (int)g.lda, (int)g.ldb, g.k1, 0};
+    sg.s[1] = GemmSeg{g.A2, g.B2, (int)g.lda2, (int)g.ldb2, g.k - g.k1, 0};
+    return launch_gemm_nt_segs(g, sg, s);
   }
   if (!g.guest && g_cu_guest && g_gemm_polite) {
     GemmNT h = g;
@@ -586,7 +640,7 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
 #define GPK_DBG_LAUNCH(D)                                                                                                 \
   do {                                                                                                                    \
     if (dyn > 0) (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<false, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); \
-    hipLaunchKernelGGL((gemm_nt8_kernel<false, true, D>), grid, block, dyn, s, g);                                        \
+    hipLaunchKernelGGL((gemm_nt8_kernel<false, true, D>), grid, block, dyn, s, g, NoSegs{});                              \
   } while (0)
     switch (dbg) {
       case 1: GPK_DBG_LAUNCH(1); break;
@@ -598,9 +652,9 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
       case 256: GPK_DBG_LAUNCH(256); break;
       case 4: GPK_DBG_LAUNCH(4); break;
       case 128: GPK_DBG_LAUNCH(128); break;
-      case 32: { GemmNT gt = g; gt.trace = g_gemm_trace; hipLaunchKernelGGL((gemm_nt8_kernel<false, true, 32>), grid, block, dyn, s, gt); } break;
-      case 544: { GemmNT gt = g; gt.trace = g_gemm_trace; hipLaunchKernelGGL((gemm_nt8_kernel<false, true, 544>), grid, block, dyn, s, gt); } break;
-      case 552: { GemmNT gt = g; gt.trace = g_gemm_trace; hipLaunchKernelGGL((gemm_nt8_kernel<false, true, 552>), grid, block, dyn, s, gt); } break;
+      case 32: { GemmNT gt = g; gt.trace = g_gemm_trace; hipLaunchKernelGGL((gemm_nt8_kernel<false, true, 32>), grid, block, dyn, s, gt, NoSegs{}); } break;
+      case 544: { GemmNT gt = g; gt.trace = g_gemm_trace; hipLaunchKernelGGL((gemm_nt8_kernel<false, true, 544>), grid, block, dyn, s, gt, NoSegs{}); } break;
+      case 552: { GemmNT gt = g; gt.trace = g_gemm_trace; hipLaunchKernelGGL((gemm_nt8_kernel<false, true, 552>), grid, block, dyn, s, gt, NoSegs{}); } break;
       default: GPK_DBG_LAUNCH(0); break;
     }
 #undef GPK_DBG_LAUNCH
@@ -608,10 +662,58 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
     return 0;
   }
 #endif
-  if (g.k1 > 0 && g.sub) hipLaunchKernelGGL((gemm_nt8_kernel<true, true>), grid, block, 0, s, g);
-  else if (g.k1 > 0) hipLaunchKernelGGL((gemm_nt8_kernel<true, false>), grid, block, 0, s, g);
-  else if (g.sub) hipLaunchKernelGGL((gemm_nt8_kernel<false, true>), grid, block, 0, s, g);
-  else hipLaunchKernelGGL((gemm_nt8_kernel<false, false>), grid, block, 0, s, g);
+  if (g.sub) hipLaunchKernelGGL((gemm_nt8_kernel<false, true>), grid, block, 0, s, g, NoSegs{});
+  else hipLaunchKernelGGL((gemm_nt8_kernel<false, false>), grid, block, 0, s, g, NoSegs{});
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gemm_nt_segs(const GemmNT& g0, const GemmSegs& segs, hipStream_t s, int persist_grid, unsigned* counter) {
+  if (g0.m <= 0 || g0.n <= 0) return 0;
+  if (g0.m % 128 || g0.n % 128) return gpk_set_err(-1, "gemm_nt_segs: bad shape m=%d n=%d", g0.m, g0.n);
+  if (g0.cyc_P != 0) return gpk_set_err(-1, "gemm_nt_segs: single-GPU column map only");
+  if (segs.n < 1 || segs.n > GPK_MAXSEG) return gpk_set_err(-1, "gemm_nt_segs: %d segments (1..%d)", segs.n, GPK_MAXSEG);
+  long ktot = 0;
+  for (int i = 0; i < segs.n; ++i) {
+    const GemmSeg& q = segs.s[i];
+    if (q.k <= 0 || q.k % BK || !q.A || !q.B || (q.lda & 1) || (q.ldb & 1) || q.lda < q.k || q.ldb < q.k || q.lda >= (1 << 22) || q.ldb >= (1 << 22) ||
+        ((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15))
+      return gpk_set_err(-1, "gemm_nt_segs: bad segment %d (k=%d lda=%d ldb=%d)", i, q.k, q.lda, q.ldb);
+    ktot += q.k;
+  }
+  if (ktot >= (1l << 30)) return gpk_set_err(-1, "gemm_nt_segs: K too large");
+  GemmNT g = g0;
+  g.k = (int)ktot;
+  g.k1 = 0;
+  g.A = segs.s[0].A; g.lda = segs.s[0].lda;  // (unused by the kernel in table mode; kept consistent for the tile decode)
+  g.B = segs.s[0].B; g.ldb = segs.s[0].ldb;
+  g.A2 = g.B2 = nullptr;
+  if (!g.guest && g_cu_guest && g_gemm_polite) g.guest = g_cu_guest;
+  const int ntm = g.m / 128, ntn = g.n / 128;
+  long nblk;
+  if (g.lower) {
+    if (g.m < g.n) return gpk_set_err(-1, "gemm_nt_segs: lower needs m >= n (m=%d n=%d)", g.m, g.n);
+    nblk = (long)ntn * (ntn + 1) / 2 + (long)(ntm - ntn) * ntn;
+  } else {
+    nblk = (long)ntm * ntn;
+  }
+  if (g.xcd_sq) {
+    const long SM = (ntm + 7) / 8, SN = (ntn + 7) / 8;
+    const long nsq = g.lower ? SN * (SN + 1) / 2 + (SM - SN) * SN : SM * SN;
+    nblk = ((nsq + 7) / 8) * 8 * 64;
+  }
+  if (persist_grid > 0 && counter && !g.xcd_sq && nblk > persist_grid) {
+    // persistent: persist_grid workgroups share the nblk tiles through `counter` (zeroed here, on the same stream)
+    GPK_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), s));
+    const dim3 pgrid((unsigned)persist_grid), block(512);
+    if (g.sub) hipLaunchKernelGGL((gemm_nt8_persistent_kernel<true>), pgrid, block, 0, s, g, segs, counter, (unsigned)nblk);
+    else hipLaunchKernelGGL((gemm_nt8_persistent_kernel<false>), pgrid, block, 0, s, g, segs, counter, (unsigned)nblk);
+    GPK_HIP(hipGetLastError());
+    return 0;
+  }
+  const dim3 grid((unsigned)nblk), block(512);
+  if (g.sub) hipLaunchKernelGGL((gemm_nt8_kernel<true, true>), grid, block, 0, s, g, segs);
+  else hipLaunchKernelGGL((gemm_nt8_kernel<true, false>), grid, block, 0, s, g, segs);
   GPK_HIP(hipGetLastError());
   return 0;
 }

@@ -1,30 +1,20 @@
 /*
- * gpk_testhooks.h -- measurement and test hooks exported by libgpk.so NEXT TO its API (include/gpk.h).
+ * gpk_testhooks.h -- test and probe hooks exported by libgpk_hooks.so (gptest_amd/csrc/gpk_hooks.hip), a library of its own
+ * on top of libgpk.so that only tests/ and scripts/ load (tests/gpk_hooks.py).  The product library exports none of them.
  *
- * Nothing here replaces a reference interface and no integration binds it: bench.py times the hot path through
- * gpk_bench_posterior / gpk_last_timing, tests/ reach single kernels and the single-process emulation of the
- * block-cyclic job through gpk_test_*, scripts/ probe the hardware through gpk_bench_* / gpk_debug_*.
+ * Nothing here replaces a reference interface and no integration binds it: tests/ reach single kernels and the
+ * single-process emulation of the block-cyclic job through gpk_test_*, scripts/ probe the hardware through gpk_bench_*.
+ * (bench.py's own measurement entry points are in gpk_bench.h and stay in libgpk.so.)
  * Same conventions as gpk.h (host pointers, row-major fp64, 0 = ok).
  */
 #ifndef GPK_TESTHOOKS_H
 #define GPK_TESTHOOKS_H
 #include "gpk.h"
+#include "gpk_bench.h"
 
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-/* ---- measurement hooks (bench.py) ----------------------------------------- */
-/* HIP-event timings (ms) of the stages of the last gpk_fit / gpk_predict on this
- * process; names: "kbuild","potrf","trailing","panel","solve_y","predict".      */
-int gpk_last_timing(const char* stage, double* ms_out, double* count_out);
-/* algorithmic work (flops for "trailing", bytes for "kbuild") of the launches summed by gpk_last_timing. */
-int gpk_last_timing_work(const char* stage, double* work_out);
-/* Stage inputs once (X,y,Z resident in HBM) and run fit+predict `reps` times
- * without any host<->device traffic inside the timed region; returns total ms.  */
-int gpk_bench_posterior(const double* X, const double* y, int N, int d, const double* log_hyp,
-                        const double* Z, int M, int warmup, int reps, double* ms_total_out,
-                        double* nlml_out, double* mean_out, double* var_out);
 
 /* ---- kernel-level test hooks (tests/ only; host buffers, row-major) --------- */
 /* C (m x n) = [C -] A (m x k) * B (n x k)^T through the MFMA kernels; tile = 128 (8-wave LDS-DMA kernel) or 64 (the
@@ -33,6 +23,9 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
  * tile = 16: the LDS-free one-tile kernel of the panel chain (m = n = k = 128 only; lower: the 16x16 tiles that touch the lower triangle). */
 int gpk_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, int sub, int lower, int tile, int k1,
                      int xcd_order);
+/* C (m x n) -= A (m x K) B (n x K)^T, K = sum ks[i], with segment i of the K range stored on its own (leading dimension
+ * lds[i] >= ks[i]): one launch of the 8-wave kernel over a K-segment table (the deferred corner update). */
+int gpk_test_gemm_segs(const double* A, const double* B, double* C, int m, int n, const int* ks, const int* lds, int nseg, int lower);
 /* the RCCL calls of the multi-rank path (broadcast on the panel stream, all-gather and all-reduce on the update
  * stream) on a one-rank communicator, payload checked: what a 1-GPU box can verify of gpk_comm.hip. */
 int gpk_test_rccl_selfcheck(int n_doubles);
@@ -46,8 +39,6 @@ int gpk_test_dist_fit(const double* X, int N, int d, const double* log_hyp, doub
  * nlml_out[P], mean_out / var_out [P][M] = what every rank ends up with. */
 int gpk_test_dist_posterior(const double* X, const double* y, int N, int d, const double* log_hyp, const double* Z,
                             int M, int P, double* nlml_out, double* mean_out, double* var_out);
-/* probe: shader clock (GHz) sampled on the panel stream while the update stream runs nbig lower updates (m, K = k). */
-int gpk_bench_clock_under_load(int m, int k, int nbig, int nsamp, double* ghz_out, double* tflops_out);
 /* probe: us per step of [leaf + nsmall GEMMs of small_m x 128 x 128] on the panel-chain stream, alone / under load. */
 int gpk_bench_chain_step(int reps, int nsmall, int small_m, double* us_alone, double* us_contended);
 /* device-resident timing of the kernel-matrix builder (mode 0 SE, 1 squared distance, 2 stores only). */
@@ -61,10 +52,6 @@ int gpk_bench_leaf(int dbg_skip, int reps, double* us_out);
 /* leaf on the chain stream, alone and while the update stream saturates the chip (reps bit 24: the full-tile form,
  * bits 16..23: dbg_skip). */
 int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended);
-/* v_mfma_f64_16x16x4_f64 issue loop with exactly waves_per_simd (1, 2, 4, 8) waves pinned on every SIMD through the LDS
-   allocation: the measured fp64 MFMA peak of this device;
-   out[6] = TFLOP/s, shader GHz, max / min waves per occupied SIMD, SIMDs occupied, TFLOP/s by the slowest wave's cycles. */
-int gpk_bench_mfma_pinned(int waves_per_simd, int iters, double* out);
 /* factor one 128x128 SPD tile: L_out (128x128 lower) and Dinv_out = inv(L); full_tile: the 1024-thread form instead of
  * the slot-sized one (bit-identical results).  Returns info. */
 int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out, int full_tile);

@@ -4,6 +4,8 @@ workgroup per CU.  Usage: python scripts/gemm_dbg.py [m [k ...]]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gptest_amd import _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from gpk_hooks import hooks  # libgpk_hooks.so: probes and test hooks live outside the product library
 _lib.init()
 l = _lib.lib()
 ms = ctypes.c_double()
@@ -13,7 +15,7 @@ m = int(sys.argv[1]) if len(sys.argv) > 1 else 7936
 ks = [int(a) for a in sys.argv[2:]] or [2048, 512, 256]
 for k in ks:
     reps = max(4, 12288 // k)
-    rc = l.gpk_bench_gemm_nt(m, 8192, k, 0, 128, reps, ctypes.byref(ms))
-    rc = l.gpk_bench_gemm_nt(m, 8192, k, 0, 128, reps, ctypes.byref(ms))
+    rc = hooks().gpk_bench_gemm_nt(m, 8192, k, 0, 128, reps, ctypes.byref(ms))
+    rc = hooks().gpk_bench_gemm_nt(m, 8192, k, 0, 128, reps, ctypes.byref(ms))
     print("polite=%s DBG=%s m=%d n=8192 k=%d: %.3f ms %.2f TFLOP/s" % (os.environ.get("GPK_POLITE", "1"), os.environ.get("GPK_GEMM_DBG", "0"), m, k, ms.value, 2.0 * m * 8192 * k / ms.value / 1e9), flush=True)
 _lib.shutdown()

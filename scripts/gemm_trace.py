@@ -7,6 +7,8 @@ import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gptest_amd import _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from gpk_hooks import hooks  # libgpk_hooks.so: probes and test hooks live outside the product library
 
 m, n, k = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (7936, 8192, 512)
 path = os.environ.get("GPK_GEMM_TRACE", "/tmp/gemm_trace.bin")
@@ -14,7 +16,7 @@ os.environ["GPK_GEMM_TRACE"] = path
 os.environ.setdefault("GPK_GEMM_DBG", "32")
 _lib.init()
 ms = ctypes.c_double()
-rc = _lib.lib().gpk_bench_gemm_nt(m, n, k, 0, 128, 3, ctypes.byref(ms))
+rc = hooks().gpk_bench_gemm_nt(m, n, k, 0, 128, 3, ctypes.byref(ms))
 print("m=%d n=%d k=%d: rc=%d %.3f ms per launch, %.2f TFLOP/s" % (m, n, k, rc, ms.value, 2.0 * m * n * k / ms.value / 1e9))
 r = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
 r = r[r[:, 0] > 0]

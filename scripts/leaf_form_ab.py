@@ -18,6 +18,8 @@ SIZES = [(16384, 8, 1024, 10), (4096, 4, 1024, 40), (8192, 8, 1024, 20), (32768,
 
 def child(opts):
     from gptest_amd import _lib
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from gpk_hooks import hooks  # libgpk_hooks.so: probes and test hooks live outside the product library
     from bench import synthetic_problem
 
     _lib.init()
@@ -27,11 +29,11 @@ def child(opts):
         _lib.set_option(k, float(v))
     P = _lib.c_double_p
     us = ctypes.c_double()
-    l.gpk_bench_leaf(0, 400, ctypes.byref(us))
+    hooks().gpk_bench_leaf(0, 400, ctypes.byref(us))
     ua, uc = ctypes.c_double(), ctypes.c_double()
-    l.gpk_bench_leaf_contended(200, ctypes.byref(ua), ctypes.byref(uc))
+    hooks().gpk_bench_leaf_contended(200, ctypes.byref(ua), ctypes.byref(uc))
     print("   leaf alone %.1f us; on the chain stream %.1f us, beside back-to-back updates %.1f us" % (us.value, ua.value, uc.value), flush=True)
-    l.gpk_bench_leaf_contended((8 << 16) | 100, ctypes.byref(ua), ctypes.byref(uc))  # phase stamps of the last leaf of each run
+    hooks().gpk_bench_leaf_contended((8 << 16) | 100, ctypes.byref(ua), ctypes.byref(uc))  # phase stamps of the last leaf of each run
     for (N, d, M, reps) in SIZES:
         X, y, Z, lh = synthetic_problem(N, d, M)
         ms, nl = ctypes.c_double(), ctypes.c_double()

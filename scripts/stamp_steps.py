@@ -29,6 +29,12 @@ while True:
 ch = [a for _, a, _ in rows]
 dif = [1e3 * (ch[i] - ch[i - 1]) for i in range(1, len(ch))]
 print("panels %d; chain done at %.3f ms; per-panel chain step (us): %s" % (len(rows), ch[-1], " ".join("%.0f" % x for x in dif)))
+cr = []
+while not math.isnan(_lib.get_option("stamp_corner_%d" % len(cr))):
+    cr.append(_lib.get_option("stamp_corner_%d" % len(cr)))
+if cr:
+    print("lazy corner from column %d: catch-up launches done at (ms): %s" % (_lib.get_option("potrf_corner_from"), " ".join("%.2f" % x for x in cr)))
+print("chain at (ms): %s" % " ".join("%.2f" % x for x in ch))
 sb = [b for _, _, b in rows]
 print("substitution lag behind the chain (us): %s" % " ".join("%.0f" % (1e3 * (b - a)) for _, a, b in rows))
 _lib.shutdown()

@@ -28,9 +28,10 @@ def golden_cases():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("gpr_") and f.endswith(".npz"))
 
 
-# every option gpk_set_option knows (16 keys: 15 schedule switches + the launch-graph switch)
+# every option gpk_set_option knows (schedule switches, the launch-graph switch, the two diagnostics)
 OPTION_KEYS = ["nb", "nb_big_until", "nb_small_from", "nb_outer", "outer_until", "lookahead", "dist_group", "tail_rows",
-               "leaf_fat_rows", "gemm_polite", "pair_update", "fuse_predict", "small_tile_below", "pred_defer_from", "tail_tile_kernel", "graphs", "stamps", "timing"]
+               "leaf_fat_rows", "gemm_polite", "pair_update", "fuse_predict", "small_tile_below", "pred_defer_from", "tail_tile_kernel",
+               "corner_from", "corner_from2", "corner_from3", "corner_chunk", "corner_last", "corner_prio", "corner_hold", "corner_grid", "graphs", "stamps", "timing"]
 
 
 @pytest.fixture(autouse=True)

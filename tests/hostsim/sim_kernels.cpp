@@ -18,7 +18,7 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t) {
   if (g.m % BT || g.n % BT || g.k % 16 || g.k <= 0) return gpk_set_err(-1, "gemm_nt: bad shape m=%d n=%d k=%d (tile %d)", g.m, g.n, g.k, BT);
   if ((g.lda & 1) || (g.ldb & 1)) return gpk_set_err(-1, "gemm_nt: odd leading dimension");
   if (g.lower && g.cyc_P == 0 && g.m < g.n) return gpk_set_err(-1, "gemm_nt: lower needs m >= n");
-  if (g.k1 > 0 && (g.k1 % 16 || g.k1 >= g.k || !g.A2 || !g.B2 || g.lda2 != g.lda || g.ldb2 != g.ldb || g.cyc_P != 0 || !tile128))
+  if (g.k1 > 0 && (g.k1 % 16 || g.k1 >= g.k || !g.A2 || !g.B2 || (g.lda2 & 1) || (g.ldb2 & 1) || g.cyc_P != 0 || !tile128))
     return gpk_set_err(-1, "gemm_nt: bad second K segment");
   const int ntm = g.m / BT, ntn = g.n / BT;
   for (int ti = 0; ti < ntm; ++ti)
@@ -46,6 +46,38 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t) {
           }
           double* c = g.C + ra * g.ldc + (long)tj * BT + j;
           *c = g.sub ? *c - acc : acc;
+        }
+    }
+  return 0;
+}
+
+// the 8-wave kernel over a K-segment table: the same tiles, every segment's rows read with its own leading dimension
+int launch_gemm_nt_segs(const GemmNT& g, const GemmSegs& segs, hipStream_t, int persist_grid, unsigned* counter) {
+  if (persist_grid > 0 && counter) *counter = 0;  // (the device form zeroes the tile counter on the stream)
+  if (g.m <= 0 || g.n <= 0) return 0;
+  if (g.m % 128 || g.n % 128 || g.cyc_P != 0) return gpk_set_err(-1, "gemm_nt_segs: bad shape m=%d n=%d", g.m, g.n);
+  if (segs.n < 1 || segs.n > GPK_MAXSEG) return gpk_set_err(-1, "gemm_nt_segs: %d segments", segs.n);
+  if (g.lower && g.m < g.n) return gpk_set_err(-1, "gemm_nt_segs: lower needs m >= n");
+  for (int i = 0; i < segs.n; ++i) {
+    const GemmSeg& q = segs.s[i];
+    if (q.k <= 0 || q.k % 16 || !q.A || !q.B || (q.lda & 1) || (q.ldb & 1) || q.lda < q.k || q.ldb < q.k) return gpk_set_err(-1, "gemm_nt_segs: bad segment %d", i);
+  }
+  const int ntm = g.m / 128, ntn = g.n / 128;
+  for (int ti = 0; ti < ntm; ++ti)
+    for (int tj = 0; tj < ntn; ++tj) {
+      if (g.lower && tj > ti) continue;
+      for (int i = 0; i < 128; ++i)
+        for (int j = 0; j < 128; ++j) {
+          const long ra = (long)ti * 128 + i, rb = (long)tj * 128 + j;
+          double* c = g.C + ra * g.ldc + rb;
+          double v = g.sub ? *c : 0.0;
+          for (int q = 0; q < segs.n; ++q) {
+            const GemmSeg& sg = segs.s[q];
+            double acc = 0.0;
+            for (int kk = 0; kk < sg.k; ++kk) acc += sg.A[ra * sg.lda + kk] * sg.B[rb * sg.ldb + kk];
+            v = g.sub ? v - acc : v + acc;
+          }
+          *c = v;
         }
     }
   return 0;

@@ -78,6 +78,66 @@ int main() {
   opt("tail_rows", 0); opt("nb", 0);
   opt("nb_outer", 2048); opt("outer_until", 8192); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
 
+  // ---- lazy corner: trapezoid updates before the boundary, catch-up launches over K-segment tables on the corner stream,
+  //      the boundary panel's update merged with the last deferred panels; with and without a tile-pipeline tail behind it.
+  //      The stand-ins apply a table segment by segment, so the factor must equal the immediate schedule's exactly.
+  {
+    opt("pair_update", 0);
+    auto spd = [](int N) {
+      vec A((size_t)N * N);
+      for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) { const double v = (i == j ? N + 1.0 : 0.0) + std::cos(0.07 * (i - j)); A[(size_t)i * N + j] = A[(size_t)j * N + i] = v; }
+      return A;
+    };
+    {
+      const int N = 900;  // eight 128-wide panels, the last four through the tile pipeline or not
+      opt("nb", 128);
+      const vec A = spd(N);
+      for (int tail : {0, 512}) {
+        opt("tail_rows", tail);
+        opt("corner_from", 0);
+        vec L0 = A;
+        CHECK(gpk_potrf(L0.data(), N) == 0 && gpk_get_option("potrf_corner_from") == 0, "immediate schedule");
+        struct { int from, chunk, last, expect, expect_tail; } cases[] = {{512, 256, 128, 512, 512}, {384, 128, 256, 384, 384}, {256, 4096, 0, 256, 256},
+                                                                           {640, 256, 128, 640, 0}, {128, 256, 128, 256, 256}, {896, 256, 128, 0, 0}};
+        for (auto& c : cases) {
+          opt("corner_from", c.from); opt("corner_chunk", c.chunk); opt("corner_last", c.last);
+          vec L1 = A;
+          const int want = tail ? c.expect_tail : c.expect;
+          CHECK(gpk_potrf(L1.data(), N) == 0, "lazy corner from %d", c.from);
+          CHECK(gpk_get_option("potrf_corner_from") == want, "lazy corner from %d: boundary %g, expected %d (tail %d)", c.from, gpk_get_option("potrf_corner_from"), want, tail);
+          CHECK(maxdiff(L0, L1) == 0.0, "lazy corner from %d chunk %d last %d tail %d: diff %g", c.from, c.chunk, c.last, tail, maxdiff(L0, L1));
+        }
+      }
+      // nested regions, held-back catch-up
+      opt("tail_rows", 0);
+      vec L0 = A;
+      opt("corner_from", 0);
+      CHECK(gpk_potrf(L0.data(), N) == 0, "immediate schedule");
+      struct { int b1, b2, b3, hold; } nest[] = {{256, 512, 768, 0}, {384, 640, 0, 256}, {256, 384, 512, 1 << 20}};
+      for (auto& c : nest) {
+        opt("corner_from", c.b1); opt("corner_from2", c.b2); opt("corner_from3", c.b3); opt("corner_hold", c.hold); opt("corner_chunk", 256); opt("corner_last", 128);
+        opt("corner_grid", c.hold ? 0 : 256);
+        vec L1 = A;
+        CHECK(gpk_potrf(L1.data(), N) == 0, "nested lazy regions %d %d %d", c.b1, c.b2, c.b3);
+        CHECK(gpk_get_option("potrf_corner_from") == c.b1 && gpk_get_option("potrf_corner_from2") == c.b2 && gpk_get_option("potrf_corner_from3") == c.b3, "nested boundaries");
+        CHECK(maxdiff(L0, L1) == 0.0, "nested lazy regions %d %d %d hold %d: diff %g", c.b1, c.b2, c.b3, c.hold, maxdiff(L0, L1));
+      }
+      opt("corner_from2", 0); opt("corner_from3", 0); opt("corner_hold", 0); opt("corner_grid", 256);
+      opt("corner_from", 512); opt("corner_chunk", 256); opt("corner_last", 128);
+      vec B((size_t)N * N, 0.0);
+      for (int i = 0; i < N; ++i) B[(size_t)i * N + i] = 2.0;
+      B[(size_t)700 * N + 700] = -1.0;
+      CHECK(gpk_potrf(B.data(), N) == 701, "not positive definite inside the corner");
+    }
+    // panels of three widths (segments with different leading dimensions in one table), posterior behind the corner
+    opt("nb", 0); opt("nb_big_until", 512); opt("nb_small_from", 384); opt("tail_rows", 0);
+    opt("corner_from", 768); opt("corner_chunk", 4096); opt("corner_last", 512);
+    check_fit_predict(make_problem(1300, 3, 30), "posterior behind a lazy corner (512 / 256 / 128 panels)");
+    CHECK(gpk_get_option("potrf_corner_from") == 768, "boundary of the three-width schedule: %g", gpk_get_option("potrf_corner_from"));
+    opt("corner_from", 0); opt("corner_chunk", 2048); opt("corner_last", 256);
+    opt("nb_big_until", 8192); opt("nb_small_from", 2048); opt("tail_rows", 0); opt("pair_update", 1);
+  }
+
   // ---- block-cyclic schedule on virtual ranks (look-ahead and plain), against the one-rank factor
   for (int la : {1, 0}) for (int grp : {1, 2, 3}) {
     opt("lookahead", la);

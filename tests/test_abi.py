@@ -1,5 +1,5 @@
 """CPU: the C-ABI shared library loads and exports every symbol include/gpk.h declares
-(gpk_testhooks.h: the measurement / test hooks exported next to it; no compute calls: there is no GPU here), and the product path fails loudly without one."""
+and include/gpk_bench.h (the test hooks of gpk_testhooks.h: libgpk_hooks.so; no compute calls: there is no GPU here), and the product path fails loudly without one."""
 import os
 import re
 
@@ -9,9 +9,9 @@ import pytest
 from conftest import ROOT
 
 
-def _declared_symbols():
+def _declared_symbols(headers):
     names = set()
-    for h in ("gpk.h", "gpk_testhooks.h"):  # the API, and the measurement / test hooks exported next to it
+    for h in headers:
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         names |= set(re.findall(r"\b(gpk_[A-Za-z0-9_]+)\s*\(", txt))
@@ -22,13 +22,39 @@ def test_library_exports_every_declared_symbol():
     from gptest_amd import _lib
 
     l = _lib.lib()
-    names = _declared_symbols()
+    names = _declared_symbols(("gpk.h", "gpk_bench.h"))  # the API, and bench.py's measurement entry points exported next to it
     assert len(names) >= 30
     for n in names:
         assert hasattr(l, n), "libgpk.so does not export %s" % n
-    # and the Python binding table covers the header (no silently unbound entry points)
+    # and the Python binding table covers the headers (no silently unbound entry points)
     assert set(names) == set(_lib.EXPORTS.keys())
     assert l.gpk_abi_version() == 1
+
+
+def test_hooks_live_in_their_own_library():
+    """include/gpk_testhooks.h is exported by libgpk_hooks.so (tests/ and scripts/ only), not by the product library."""
+    import subprocess
+
+    from gptest_amd import _lib
+    import gpk_hooks
+
+    h = gpk_hooks.hooks()
+    names = set(_declared_symbols(("gpk_testhooks.h",))) - set(_declared_symbols(("gpk.h", "gpk_bench.h")))
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(h, n), "libgpk_hooks.so does not export %s" % n
+    assert names == set(gpk_hooks.EXPORTS.keys())
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib._LIB_PATH], check=True, stdout=subprocess.PIPE, text=True).stdout
+    exported = set(re.findall(r"\b(gpk_[A-Za-z0-9_]+)$", syms, flags=re.M))
+    assert not [n for n in exported if n.startswith("gpk_test_")], "the product library exports test hooks"
+    assert not (exported & names), exported & names
+    # nothing in the product, bench.py or the smoke entry loads the hooks library
+    for f in ("bench.py", "__graft_entry__.py"):
+        assert "gpk_hooks" not in open(os.path.join(ROOT, f)).read().replace("libgpk_hooks.so", "")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gptest_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "gpk_hooks" not in open(os.path.join(dirpath, f)).read(), f
 
 
 def test_no_cpu_fallback_without_gpu():

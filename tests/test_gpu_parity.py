@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, golden_cases
+from gpk_hooks import hooks
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +36,7 @@ def test_mfma_gemm_nt(gpk, m, n, k, tile, sub, lower):
     B = A.copy() if lower else rng.randn(n, k)
     C0 = rng.randn(m, n)
     C = C0.copy()
-    rc = gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, tile, 0, 0)
+    rc = hooks().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, tile, 0, 0)
     assert rc == 0, gpk.last_error()
     ref = C0 - A @ B.T if sub else A @ B.T
     if lower:
@@ -60,7 +61,7 @@ def test_mfma_gemm_nt_lower_trapezoid(gpk, m, n, k, tile):
     B = np.ascontiguousarray(A[:n])
     for xcd in ((0, 1) if tile == 128 else (0,)):  # 1: force the XCD-aware 8x8-square tile order of the big updates
         C[:] = C0
-        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, 1, tile, 0, xcd) == 0, gpk.last_error()
+        assert hooks().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, 1, tile, 0, xcd) == 0, gpk.last_error()
         ref = C0 - A @ B.T
         mask = np.zeros((m, n), bool)
         for ti in range(m // tile):
@@ -83,7 +84,7 @@ def test_lds_dma_kernel_is_bitwise_the_register_staged_kernel(gpk, m, n, k, sub,
 
     def run(tile, k1=0, xcd=0):
         C = C0.copy()
-        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, tile, k1, xcd) == 0, gpk.last_error()
+        assert hooks().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, sub, lower, tile, k1, xcd) == 0, gpk.last_error()
         return C
 
     ref64 = run(64)
@@ -117,7 +118,7 @@ def test_tile_sizes_round_identically(gpk, sub):
     out = []
     for tile in (64, 128):
         C = C0.copy()
-        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 256, 384, 96, sub, 0, tile, 0, 0) == 0
+        assert hooks().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 256, 384, 96, sub, 0, tile, 0, 0) == 0
         out.append(C)
     np.testing.assert_array_equal(out[0], out[1])
 
@@ -134,7 +135,7 @@ def test_one_tile_chain_kernel_is_bitwise_the_tile_kernels(gpk, sub, lower):
     out = {}
     for tile in (16, 64, 128):
         C = C0.copy()
-        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 128, 128, 128, sub, lower, tile, 0, 0) == 0, gpk.last_error()
+        assert hooks().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 128, 128, 128, sub, lower, tile, 0, 0) == 0, gpk.last_error()
         out[tile] = C
     touched = np.ones((128, 128), bool)
     if lower:
@@ -146,7 +147,7 @@ def test_one_tile_chain_kernel_is_bitwise_the_tile_kernels(gpk, sub, lower):
     np.testing.assert_allclose(out[16][touched], ref[touched], rtol=1e-12, atol=1e-12)
     # anything but one 128 x 128 x 128 product is refused
     C = np.zeros((256, 128))
-    assert gpk.lib().gpk_test_gemm_nt(_ptr(rng.randn(256, 128)), _ptr(B), _ptr(C), 256, 128, 128, 0, 0, 16, 0, 0) != 0
+    assert hooks().gpk_test_gemm_nt(_ptr(rng.randn(256, 128)), _ptr(B), _ptr(C), 256, 128, 128, 0, 0, 16, 0, 0) != 0
 
 
 @pytest.mark.parametrize("m,n,k,k1,lower", [(256, 384, 256, 128, 0), (512, 512, 384, 256, 1), (2048, 2048, 768, 512, 1)])
@@ -160,9 +161,50 @@ def test_two_segment_k_is_bitwise_one_update(gpk, m, n, k, k1, lower):
     out = []
     for split in (0, k1):
         C = C0.copy()
-        assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, lower, 128, split, 0) == 0, gpk.last_error()
+        assert hooks().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), m, n, k, 1, lower, 128, split, 0) == 0, gpk.last_error()
         out.append(C)
     np.testing.assert_array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("m,n,lower,ks,lds", [
+    (256, 384, 0, (16, 32, 16), (16, 40, 18)),                                   # one-slab segments, ragged leading dimensions
+    (512, 512, 1, (256, 128, 128, 512), (256, 128, 512, 512)),                   # panels of three widths, one stored inside a wider one
+    (1280, 768, 1, (512,) * 5 + (256,) * 6, (512,) * 5 + (256,) * 6),            # lower trapezoid, 11 segments
+    (2048, 2048, 1, (128,) * 32, (128,) * 32),                                   # the table's capacity
+])
+def test_k_segment_table_is_bitwise_one_update_per_segment(gpk, m, n, lower, ks, lds):
+    """The deferred corner update reads its K range from up to 32 separately stored panels (each with its own leading
+    dimension) in ONE launch.  The MFMA chain of every output element starts from the stored C and runs over k in table
+    order, so the result must be the very bits of (a) the single-operand product over the concatenated K range and (b) one
+    launch per segment, in order."""
+    K = sum(ks)
+    rng = np.random.RandomState(K + m)
+    A = rng.randn(m, K)
+    B = A[:n].copy() if lower else rng.randn(n, K)
+    C0 = rng.randn(m, n)
+    ks_c = (ctypes.c_int * len(ks))(*ks)
+    lds_c = (ctypes.c_int * len(ks))(*lds)
+    C1 = C0.copy()
+    assert hooks().gpk_test_gemm_segs(_ptr(A), _ptr(B), _ptr(C1), m, n, ks_c, lds_c, len(ks), lower) == 0, gpk.last_error()
+    C2 = C0.copy()
+    assert hooks().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C2), m, n, K, 1, lower, 128, 0, 0) == 0, gpk.last_error()
+    C3 = C0.copy()
+    k0 = 0
+    for k in ks:
+        Ak, Bk = np.ascontiguousarray(A[:, k0:k0 + k]), np.ascontiguousarray(B[:, k0:k0 + k])
+        assert hooks().gpk_test_gemm_nt(_ptr(Ak), _ptr(Bk), _ptr(C3), m, n, k, 1, lower, 128, 0, 0) == 0, gpk.last_error()
+        k0 += k
+    if lower:  # tiles above the diagonal are not touched by any of the three
+        tri = np.kron(np.tril(np.ones((m // 128, n // 128))), np.ones((128, 128))).astype(bool)
+        assert np.array_equal(C1[~tri], C0[~tri])
+    np.testing.assert_array_equal(C1, C2)
+    np.testing.assert_array_equal(C1, C3)
+    ref = C0 - A @ B.T
+    sel = tri if lower else np.ones_like(C0, dtype=bool)
+    np.testing.assert_allclose(C1[sel], ref[sel], rtol=1e-10, atol=1e-10 * np.abs(ref).max())
+    # malformed tables are refused
+    bad = (ctypes.c_int * 1)(24)
+    assert hooks().gpk_test_gemm_segs(_ptr(A), _ptr(B), _ptr(C1), m, n, bad, bad, 1, lower) != 0
 
 
 def test_mfma_fragment_layout_identity(gpk):
@@ -171,7 +213,7 @@ def test_mfma_fragment_layout_identity(gpk):
     A[:16, :16] = np.eye(16)
     B = np.arange(128 * 16, dtype=float).reshape(128, 16) + 0.25
     C = np.zeros((128, 128))
-    assert gpk.lib().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 128, 128, 16, 0, 0, 128, 0, 0) == 0
+    assert hooks().gpk_test_gemm_nt(_ptr(A), _ptr(B), _ptr(C), 128, 128, 16, 0, 0, 128, 0, 0) == 0
     np.testing.assert_array_equal(C, A @ B.T)
 
 
@@ -181,16 +223,16 @@ def test_leaf_factor_and_inverse(gpk):
     A = Q @ Q.T + 128 * np.eye(128)
     L = np.zeros((128, 128))
     D = np.zeros((128, 128))
-    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), 0) == 0
+    assert hooks().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), 0) == 0
     Lr = np.linalg.cholesky(A)
     np.testing.assert_allclose(L, Lr, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(D @ Lr, np.eye(128), atol=1e-12)
     assert np.all(np.triu(L, 1) == 0) and np.all(np.triu(D, 1) == 0)
     # first non-positive pivot is reported LAPACK-style (1-based)
     A[7, 7] = -3.0
-    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), 0) == 8
+    assert hooks().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), 0) == 8
     A[:] = np.nan
-    assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), 1) == 1
+    assert hooks().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), 1) == 1
 
 
 def test_slot_sized_leaf_is_bitwise_the_full_tile_leaf(gpk):
@@ -206,7 +248,7 @@ def test_slot_sized_leaf_is_bitwise_the_full_tile_leaf(gpk):
         out = []
         for full in (1, 0):
             L, D = np.zeros((128, 128)), np.zeros((128, 128))
-            assert gpk.lib().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), full) == 0, gpk.last_error()
+            assert hooks().gpk_test_potf2_128(_ptr(A), _ptr(L), _ptr(D), full) == 0, gpk.last_error()
             out.append((L, D))
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
         assert np.all(np.triu(out[1][0], 1) == 0) and np.all(np.triu(out[1][1], 1) == 0)
@@ -217,7 +259,7 @@ def test_slot_sized_leaf_is_bitwise_the_full_tile_leaf(gpk):
         B[bad, bad] = -1.0
         for full in (1, 0):
             L, D = np.zeros((128, 128)), np.zeros((128, 128))
-            assert gpk.lib().gpk_test_potf2_128(_ptr(B), _ptr(L), _ptr(D), full) == bad + 1
+            assert hooks().gpk_test_potf2_128(_ptr(B), _ptr(L), _ptr(D), full) == bad + 1
             assert np.array_equal(L, np.eye(128)) and np.array_equal(D, np.eye(128))  # identity factors keep downstream kernels finite
 
 
@@ -314,6 +356,100 @@ def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_fro
     B = np.eye(N) * 2.0
     B[N - 70, N - 70] = -1.0
     assert gpk.lib().gpk_potrf(_ptr(B), N) == N - 69
+
+
+@pytest.mark.parametrize("N,opts,cases", [
+    # 512 / 256 / 128 panels at a quarter of the production thresholds, tile pipeline behind the corner
+    (4000, {"nb_big_until": 2048, "nb_small_from": 1024, "tail_rows": 1024},
+     [(2560, 1024, 256, 2560), (2560, 512, 1024, 2560), (2048, 8192, 0, 2048), (3072, 1024, 256, 3072), (2176, 768, 512, 2304), (3200, 1024, 256, 0)]),
+    # no tile pipeline: the boundary panel's look-ahead and rest updates both run over a segment table
+    (3000, {"nb_big_until": 1024, "nb_small_from": 512, "tail_rows": 0}, [(2048, 512, 768, 2048), (1536, 4096, 256, 1536), (2816, 1024, 128, 2816)]),
+    # uniform 128-wide panels: tables at capacity (32 segments per launch)
+    (5000, {"nb": 128, "tail_rows": 512}, [(4352, 4096, 128, 4352), (4608, 1024, 4096, 4608)]),
+])
+def test_lazy_corner_is_bitwise_the_immediate_schedule(gpk, N, opts, cases):
+    """Option corner_from: panels in front of the boundary b update the trapezoid of columns < b only; the corner [b:, b:] gets
+    their updates later, in panel order, from a few high-K launches over K-segment tables on the corner stream, the last
+    corner_last columns together with the boundary panel's own update.  Every element receives the same rank-w updates in the
+    same order inside MFMA chains that start from the stored value: the factor must be the immediate schedule's bit for
+    bit, whatever the boundary, the chunking and the stream priority -- also with a non-positive pivot inside the corner."""
+    rng = np.random.RandomState(N)
+    Q = rng.randn(N, N)
+    A = Q @ Q.T + N * np.eye(N)
+    for k, v in opts.items():
+        gpk.set_option(k, v)
+    gpk.set_option("pair_update", 0)
+    gpk.set_option("corner_from", 0)
+    L0 = A.copy()
+    assert gpk.lib().gpk_potrf(_ptr(L0), N) == 0, gpk.last_error()
+    assert gpk.get_option("potrf_corner_from") == 0
+    for i, (frm, chunk, last, expect) in enumerate(cases):
+        gpk.set_option("corner_from", frm)
+        gpk.set_option("corner_chunk", chunk)
+        gpk.set_option("corner_last", last)
+        gpk.set_option("corner_prio", i % 3)
+        gpk.set_option("corner_grid", (256, 0, 37, 512)[i % 4])  # persistent catch-up launches (one workgroup per CU; odd; all slots) or one workgroup per tile
+        L1 = A.copy()
+        assert gpk.lib().gpk_potrf(_ptr(L1), N) == 0, gpk.last_error()
+        assert gpk.get_option("potrf_corner_from") == expect, (frm, gpk.get_option("potrf_corner_from"))
+        np.testing.assert_array_equal(L1, L0, err_msg=str((frm, chunk, last)))
+    # nested regions (up to three boundaries; the later regions' catch-up held back until the chain reaches the boundary in
+    # front of them) and a held-back first region
+    frm = cases[0][0]
+    Npad = (N + 127) // 128 * 128
+    for b2, b3, hold in ((frm + 512, 0, 0), (frm + 256, frm + 512, frm - 512), (Npad, 0, 1 << 20)):
+        gpk.set_option("corner_from", frm)
+        gpk.set_option("corner_from2", b2)
+        gpk.set_option("corner_from3", b3)
+        gpk.set_option("corner_hold", hold)
+        gpk.set_option("corner_chunk", 768)
+        gpk.set_option("corner_last", 256)
+        L1 = A.copy()
+        assert gpk.lib().gpk_potrf(_ptr(L1), N) == 0, gpk.last_error()
+        assert gpk.get_option("potrf_corner_from") == cases[0][3]
+        np.testing.assert_array_equal(L1, L0, err_msg=str((frm, b2, b3, hold)))
+    gpk.set_option("corner_from2", 0)
+    gpk.set_option("corner_from3", 0)
+    gpk.set_option("corner_hold", 0)
+    Lr = np.linalg.cholesky(A)
+    np.testing.assert_allclose(L0, Lr, rtol=1e-11, atol=1e-11 * np.abs(Lr).max())
+    gpk.set_option("corner_from", frm)
+    gpk.set_option("corner_chunk", cases[0][1])
+    gpk.set_option("corner_last", cases[0][2])
+    for bad in (frm + 70, frm - 300, N - 5):  # inside the corner, in front of it, in the last tile
+        B = np.eye(N) * 2.0
+        B[bad, bad] = -1.0
+        assert gpk.lib().gpk_potrf(_ptr(B), N) == bad + 1
+
+
+def test_lazy_corner_posterior_matches_oracle(gpk):
+    """The whole fused posterior (pipelined substitutions, deferred prediction updates) behind a lazy corner: the very bits of
+    the immediate schedule, and the oracle's numbers."""
+    from oracle import gpr_oracle as orc
+    N, d, M = 4096, 4, 300
+    X, y, Z, lh = orc.synthetic_problem(N, d, M, seed=7)
+    hc = np.ascontiguousarray(lh)
+    for k, v in {"nb_big_until": 2048, "nb_small_from": 1024, "tail_rows": 1024, "pred_defer_from": 2048}.items():
+        gpk.set_option(k, v)
+
+    def posterior():
+        ms, nl = ctypes.c_double(), ctypes.c_double()
+        mean, var = np.zeros(M), np.zeros(M)
+        rc = gpk.lib().gpk_bench_posterior(_ptr(X), _ptr(y), N, d, _ptr(hc), _ptr(Z), M, 0, 1, ctypes.byref(ms), ctypes.byref(nl), _ptr(mean), _ptr(var))
+        assert rc == 0, gpk.last_error()
+        return nl.value, mean, var
+
+    gpk.set_option("corner_from", 0)
+    n0, m0, v0 = posterior()
+    gpk.set_option("corner_from", 2560)
+    gpk.set_option("corner_chunk", 1024)
+    n1, m1, v1 = posterior()
+    assert gpk.get_option("potrf_corner_from") == 2560
+    assert n1 == n0 and np.array_equal(m1, m0) and np.array_equal(v1, v0)
+    nl_o, fz_o, cov_o = orc.posterior_efficient(lh, X, y, Z)
+    assert abs(n0 - float(np.ravel(nl_o)[0])) <= RTOL * abs(float(np.ravel(nl_o)[0]))
+    np.testing.assert_allclose(m0, fz_o, rtol=RTOL, atol=RTOL * np.abs(fz_o).max())
+    np.testing.assert_allclose(v0, cov_o, rtol=RTOL, atol=RTOL * np.abs(cov_o).max())
 
 
 @pytest.mark.parametrize("N,d,M,opts,cols", [
@@ -658,9 +794,9 @@ def test_block_cyclic_cholesky_emulated_ranks(gpk, N, P, nb, lookahead, group):
     gpk.set_option("lookahead", lookahead)
     gpk.set_option("dist_group", group)   # panels per ownership block (1: every panel changes hands)
     L1 = np.empty((N, N))
-    assert gpk.lib().gpk_test_dist_potrf(_ptr(A), N, 1, _ptr(L1)) == 0, gpk.last_error()
+    assert hooks().gpk_test_dist_potrf(_ptr(A), N, 1, _ptr(L1)) == 0, gpk.last_error()
     LP = np.empty((N, N))
-    assert gpk.lib().gpk_test_dist_potrf(_ptr(A), N, P, _ptr(LP)) == 0, gpk.last_error()
+    assert hooks().gpk_test_dist_potrf(_ptr(A), N, P, _ptr(LP)) == 0, gpk.last_error()
     nP = -(-N // nb)
     assert gpk.get_option("dist_lookahead_used") == (1 if lookahead and nP >= 3 else 0)
     Lr = np.linalg.cholesky(A)
@@ -684,7 +820,7 @@ def test_block_cyclic_posterior_emulated_ranks(gpk, N, d, M, P, nb, group):
     nl = np.zeros(P)
     mean = np.zeros((P, M))
     var = np.zeros((P, M))
-    rc = gpk.lib().gpk_test_dist_posterior(_ptr(X), _ptr(y), N, d, _ptr(np.ascontiguousarray(lh)), _ptr(Z), M, P,
+    rc = hooks().gpk_test_dist_posterior(_ptr(X), _ptr(y), N, d, _ptr(np.ascontiguousarray(lh)), _ptr(Z), M, P,
                                            _ptr(nl), _ptr(mean), _ptr(var))
     assert rc == 0, gpk.last_error()
     assert gpk.get_option("dist_lookahead_used") == 1
@@ -709,7 +845,7 @@ def test_block_cyclic_not_positive_definite(gpk):
     A[700, 700] = -1.0
     L = np.empty((900, 900))
     gpk.set_option("nb", 128)
-    assert gpk.lib().gpk_test_dist_potrf(_ptr(A), 900, 4, _ptr(L)) == 701
+    assert hooks().gpk_test_dist_potrf(_ptr(A), 900, 4, _ptr(L)) == 701
     assert gpk.get_option("dist_lookahead_used") == 1
 
 
@@ -915,11 +1051,11 @@ def test_block_cyclic_fit_emulated_ranks(gpk, N, d, P):
     LP = np.empty((N, N))
     lhc = np.ascontiguousarray(lh)
     gpk.set_option("nb", 256)
-    rc = gpk.lib().gpk_test_dist_fit(_ptr(np.ascontiguousarray(X)), N, d, _ptr(lhc), 0.0, P, _ptr(LP))
+    rc = hooks().gpk_test_dist_fit(_ptr(np.ascontiguousarray(X)), N, d, _ptr(lhc), 0.0, P, _ptr(LP))
     assert rc == 0, gpk.last_error()
     assert gpk.get_option("dist_lookahead_used") == 1
     L1 = np.empty((N, N))
-    rc = gpk.lib().gpk_test_dist_fit(_ptr(np.ascontiguousarray(X)), N, d, _ptr(lhc), 0.0, 1, _ptr(L1))
+    rc = hooks().gpk_test_dist_fit(_ptr(np.ascontiguousarray(X)), N, d, _ptr(lhc), 0.0, 1, _ptr(L1))
     assert rc == 0, gpk.last_error()
     np.testing.assert_array_equal(LP, L1)
     Lr = np.linalg.cholesky(orc.kxx(lh, X))
@@ -1041,7 +1177,7 @@ def test_c4_sharded_over_8_emulated_ranks(gpk):
     nl = np.zeros(P)
     mean = np.zeros((P, M))
     var = np.zeros((P, M))
-    rc = gpk.lib().gpk_test_dist_posterior(_ptr(X), _ptr(y), N, d, _ptr(np.ascontiguousarray(lh)), _ptr(Z), M, P,
+    rc = hooks().gpk_test_dist_posterior(_ptr(X), _ptr(y), N, d, _ptr(np.ascontiguousarray(lh)), _ptr(Z), M, P,
                                            _ptr(nl), _ptr(mean), _ptr(var))
     assert rc == 0, gpk.last_error()
     assert gpk.get_option("dist_lookahead_used") == 1
@@ -1443,7 +1579,7 @@ def test_rccl_calls_on_a_one_rank_communicator(gpk):
     """All a 1-GPU box can check of gpk_comm.hip: panel-sized ncclBroadcast on a high-priority stream (as the communication
     stream is), ncclAllGather and ncclAllReduce on the update stream, on a one-rank communicator, payload intact.  (The
     multi-rank branches run with 2 and 4 real processes on the CPU: tests/test_hostsim.py.)"""
-    assert gpk.lib().gpk_test_rccl_selfcheck(16384 * 256) == 0, gpk.last_error()
+    assert hooks().gpk_test_rccl_selfcheck(16384 * 256) == 0, gpk.last_error()
 
 
 # ----------------------------------------------------------------------------- API edges
@@ -1513,14 +1649,14 @@ _lib.init()
 l = _lib.lib()
 ms = ctypes.c_double()
 for lower in (1, 0, 1, 0):
-    assert l.gpk_bench_se_build(4096, 8, 0, lower, 5, ctypes.byref(ms)) == 0
+    assert hooks().gpk_bench_se_build(4096, 8, 0, lower, 5, ctypes.byref(ms)) == 0
 _lib.shutdown()                                  # explicit: every stream, event and pooled buffer is released
 rng = np.random.RandomState(0)
 X = rng.rand(700, 2); y = rng.randn(700); lh = np.log([0.5, 0.5, 1.0, 0.1])
 h, nl = GPr.fit_handle(X, y, lh)                 # re-initialises
 assert np.isfinite(nl)
 for lower in (1, 0):
-    assert l.gpk_bench_se_build(4096, 8, 0, lower, 5, ctypes.byref(ms)) == 0
+    assert hooks().gpk_bench_se_build(4096, 8, 0, lower, 5, ctypes.byref(ms)) == 0
 print("child done", flush=True)                  # the interpreter-exit handler shuts down again
 """ % ROOT
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
