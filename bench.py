@@ -119,6 +119,72 @@ def parity_check(N, d, M, nlml, mean, var, lh):
     return ok, detail, ok
 
 
+def phase_split(l, _lib, X, y, Z, lh, N, d, M):
+    """roofline.phases: one extra posterior AFTER the timed region with the library's device-side stamps on (a one-wave kernel
+    behind every panel of the chain; no profiler), split where the panel chain leaves the widest (512-column) panels: up to
+    there the bulk updates are the bound, behind it the chain of dependent leaf / panel kernels is.  Work per phase is what the
+    schedule issues in it: trailing updates m^2 w and panel solves of its panels, the prediction's substitution updates (the far
+    part of the early panels counted where the deferred schedule runs it), the lazy-corner catch-up where it runs."""
+    P = _lib.c_double_p
+    _lib.check(l.gpk_set_option(b"stamps", 1.0), "stamps")
+    ms, nl = ctypes.c_double(), ctypes.c_double()
+    mean, var = np.zeros(M), np.zeros(M)
+    try:
+        rc = l.gpk_bench_posterior(X.ctypes.data_as(P), y.ctypes.data_as(P), N, d, lh.ctypes.data_as(P), Z.ctypes.data_as(P), M, 1, 1,
+                                   ctypes.byref(ms), ctypes.byref(nl), mean.ctypes.data_as(P), var.ctypes.data_as(P))
+        if rc != 0:
+            return None
+        g = lambda k: l.gpk_get_option(k.encode())
+        nP = int(g("last_panels"))
+        c0 = [int(g("last_panel_c0_%d" % p)) for p in range(nP)]
+        w = [int(g("last_panel_w_%d" % p)) for p in range(nP)]
+        st = [g("stamp_panel_%d" % p) for p in range(nP)]
+        t_start = g("stamp_start")
+        if nP < 3 or any(x != x for x in st) or t_start != t_start:
+            return None
+        npad = c0[-1] + w[-1]
+        mpad = (M + 127) // 128 * 128
+        wmax = max(w)
+        p1 = next((p for p in range(nP) if w[p] != wmax), nP)  # first panel that is not of the widest kind
+        if p1 in (0, nP):
+            return None
+        pdc = int(g("pred_defer_col"))
+        cb = int(g("potrf_corner_from"))
+        work = [0.0, 0.0]
+        for p in range(nP):
+            ph = 0 if p < p1 else 1
+            ce = c0[p] + w[p]
+            mm = float(npad - ce)
+            # factorisation: trailing update (the part behind a lazy-corner boundary runs with the catch-up launches: phase 2) + panel solves
+            if cb and ce < cb:
+                cm = float(npad - cb)
+                work[ph] += (mm * mm - cm * cm) * w[p]
+                work[1] += cm * cm * w[p]
+            else:
+                work[ph] += mm * mm * w[p]
+            work[ph] += float(npad - c0[p]) * w[p] * w[p]
+            # prediction: diagonal solve + update of the columns behind the panel (far part deferred to the boundary: phase of that panel)
+            work[ph] += 2.0 * mpad * w[p] * w[p] / 2
+            if pdc and ce <= pdc:
+                work[ph] += 2.0 * mpad * (pdc - ce) * w[p]
+                bph = 0 if pdc < c0[p1] else 1
+                work[bph] += 2.0 * mpad * (npad - pdc) * w[p]
+            else:
+                work[ph] += 2.0 * mpad * mm * w[p]
+        t1 = st[p1] - t_start          # the chain has left the widest panels
+        t_all = ms.value               # one posterior, stamps on
+        t2 = t_all - t1
+        return {
+            "bulk_bound": {"ms": t1, "tflop": work[0] / 1e12, "tflops": work[0] / (t1 * 1e-3) / 1e12, "panels": "%d x %d columns" % (p1, wmax)},
+            "chain_bound": {"ms": t2, "tflop": work[1] / 1e12, "tflops": work[1] / (t2 * 1e-3) / 1e12,
+                            "panels": "%d (narrower panels, tile pipeline)" % (nP - p1), "chain_done_ms": st[-1] - t_start},
+            "whole_posterior": {"ms": t_all, "tflop": (work[0] + work[1]) / 1e12, "tflops": (work[0] + work[1]) / (t_all * 1e-3) / 1e12},
+            "note": "one posterior after the timed region with device-side stamps on (no profiler); work = what the schedule issues in each phase",
+        }
+    finally:
+        l.gpk_set_option(b"stamps", 0.0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +196,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="skip roofline.sustained (its 24 extra update launches would be counted by the kernel-trace / PMC scripts)")
+    ap.add_argument("--no-phases", action="store_true", help="skip roofline.phases (one extra posterior with device stamps after the timed region)")
     ap.add_argument("--opt", action="append", default=[], help="libgpk option key=value (experiments; defaults are the product)")
     args = ap.parse_args()
 
@@ -253,14 +320,20 @@ def main():
                 if l.gpk_bench_clock_under_load(16128, 512, 24, ns, ghz, ctypes.byref(tfu)) == 0:
                     g = [x for x in list(ghz)[1:] if x > 0]
                     if g:
-                        mean = sum(g) / len(g)
-                        sustained = {"shader_clock_ghz_under_update": mean, "min": min(g), "idle": ghz[0],
-                                     "ceiling_tflops_at_that_clock": 256 * 4 * 32 * mean * 1e-3,
+                        ghz_mean = sum(g) / len(g)
+                        sustained = {"shader_clock_ghz_under_update": ghz_mean, "min": min(g), "idle": ghz[0],
+                                     "ceiling_tflops_at_that_clock": 256 * 4 * 32 * ghz_mean * 1e-3,
                                      "update_alone_tflops": tfu.value,
-                                     "frac_of_that_ceiling_in_situ": ach / (256 * 4 * 32 * mean * 1e-3),
+                                     "frac_of_that_ceiling_in_situ": ach / (256 * 4 * 32 * ghz_mean * 1e-3),
                                      "note": "one-wave clock probe beside 24 back-to-back lower updates (m = 16128, K = 512), after the timed region"}
             except Exception:
                 pass
+        phases = None
+        if world == 1 and not args.no_phases:
+            try:
+                phases = phase_split(l, _lib, X, y, Z, lh, N, d, M)
+            except Exception:
+                phases = None
         out = {
             "metric": "GP posterior solves/sec (N=%d, d=%d, M=%d; fit + predict sharing one Cholesky)" % (N, d, M),
             "value": args.steps / (t_ms * 1e-3),
@@ -284,6 +357,7 @@ def main():
                          "frac": ach / PEAK_FP64_MFMA_TFLOPS, "peak_measured": peak_measured, "sustained": sustained,
                          "traffic": traffic, "traffic_note": traffic_note,
                          "mfma_pmc_serialised": mfma_pmc,
+                         "phases": phases,
                          "launches": tr_n, "avg_launch_ms": tr_ms / tr_n if tr_n else None,
                          "alg_flops_per_step_in_timed_launches": flops},
             "kbuild": {"kernel": "se_build_kernel", "bound": "hbm", "ms": kb_ms / kb_n if kb_n else None, "unit": "GB/s",

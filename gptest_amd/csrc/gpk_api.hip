@@ -68,6 +68,21 @@ int gpk_init(int device) {
     GPK_HIP(hipDeviceSynchronize());
     (void)hipFree(dtouch);
   }
+  {
+    // cross-stream flags (fused chain step of the tile pipeline): a kernel on the chain stream must see a flag that a LATER launch
+    // on the update stream sets while it runs.  True on the plain runtime; not under a tool that serialises dispatches.
+    G.flags_ok = 0;
+    unsigned* dpr = nullptr;
+    GPK_HIP(hipMalloc((void**)&dpr, 2 * sizeof(unsigned)));
+    GPK_HIP(hipMemset(dpr, 0, 2 * sizeof(unsigned)));
+    GPK_TRY(launch_flag_probe(dpr, 1u, dpr + 1, G.s_panel));
+    GPK_TRY(launch_flag_set(dpr, 1u, G.s_main));
+    GPK_HIP(hipDeviceSynchronize());
+    unsigned seen = 0;
+    GPK_HIP(hipMemcpy(&seen, dpr + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+    (void)hipFree(dpr);
+    G.flags_ok = seen ? 1 : 0;
+  }
   G.inited = true;
   return 0;
 }
@@ -147,6 +162,8 @@ int gpk_set_option(const char* key, double value) {
     G.pair_update = v;
   } else if (k == "fuse_predict") {
     G.fuse_predict = v;
+  } else if (k == "chain_fused") {
+    G.chain_fused = v < 0 ? -1 : (v > 2 ? 2 : v);
   } else if (k == "small_tile_below") {
     G.small_tile_below = v;
   } else if (k == "tail_tile_kernel") {
@@ -202,6 +219,9 @@ double gpk_get_option(const char* key) {
   if (k == "pair_update") return G.pair_update;
   if (k == "fuse_predict") return G.fuse_predict;
   if (k == "small_tile_below") return G.small_tile_below;
+  if (k == "chain_fused") return G.chain_fused;
+  if (k == "flags_ok") return G.flags_ok;
+  if (k == "potrf_chain_fused") { extern int g_potrf_chain_fused; return g_potrf_chain_fused; }
   if (k == "pred_defer_from") return G.pred_defer_from;
   if (k == "tail_tile_kernel") return G.tail_tile_kernel;
   if (k == "corner_from") return G.corner_from;
@@ -227,12 +247,25 @@ double gpk_get_option(const char* key) {
   if (k == "pipe_enqueue_ms") return G.last_pipe_enqueue_ms;
   if (k == "potrf_lookahead_used") return g_potrf_lookahead_used;
   if (k == "dist_lookahead_used") return g_dist_lookahead_used;
+  if (k == "dist_pipelined") return g_dist_pipelined;
   if (k == "potrf_tail_from") { extern int g_potrf_tail_from; return g_potrf_tail_from; }
+  {
+    extern std::vector<int> g_last_pc0, g_last_pw;
+    if (k == "last_panels") return (double)g_last_pc0.size();
+    if (k.rfind("last_panel_c0_", 0) == 0 || k.rfind("last_panel_w_", 0) == 0) {
+      const bool c0 = k[11] == 'c';
+      const int p = atoi(k.c_str() + (c0 ? 14 : 13));
+      if (p < 0 || p >= (int)g_last_pc0.size()) return NAN;
+      return c0 ? g_last_pc0[p] : g_last_pw[p];
+    }
+    if (k == "pred_defer_col") { extern int g_pred_defer_col; return g_pred_defer_col; }
+  }
   // diagnostic stamps of the last fused fit: "stamp_panel_<p>" / "stamp_subst_<p>" in ms after panel 0
   if (k.rfind("stamp_", 0) == 0 && G.hstamps.size() == 1024 && G.hstamps[0]) {
+    if (k == "stamp_start") return G.hstamps[447] ? (double)((long long)(G.hstamps[447] - G.hstamps[0])) * 1e-5 : NAN;  // (negative: ms before panel 0 was factored)
     const bool subst = k.rfind("stamp_subst_", 0) == 0, corner = k.rfind("stamp_corner", 0) == 0;  // "stamp_corner_<j>": catch-up launch j of the lazy corner done
     const int p = atoi(k.c_str() + (corner ? 13 : 12));
-    if (p < 0 || p >= (corner ? 64 : 448)) return NAN;
+    if (p < 0 || p >= (corner ? 64 : 447)) return NAN;
     const unsigned long long v = G.hstamps[(subst ? 512 : corner ? 448 : 0) + p];
     return v ? (double)((long long)(v - G.hstamps[0])) * 1e-5 : NAN;
   }
@@ -338,6 +371,7 @@ int gpk_potrf(double* A, int N) {
     int hinfo = 0;
     if (hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = gpk_set_err(-2, "D2H failed"); break; }
     if (hipStreamSynchronize(s) != hipSuccess) { rc = gpk_set_err(-2, "potrf: %s", hipGetErrorString(hipGetLastError())); break; }
+    if ((rc = info_timeout_rc(hinfo)) != 0) break;
     if (hinfo > 0) { rc = hinfo > N ? N : hinfo; gpk_set_err(rc, "matrix is not positive definite (leading minor %d)", rc); break; }
     rc = model_unpack_L(m, A);
   } while (0);
@@ -405,8 +439,8 @@ int gpk_fit_predict(const double* X, const double* y, int N, int d, const double
       FusedPredict fp{dZ, M, Mpad, dR, dV, dmv, dmv + Mpad, mean_out, var_out};
       rc = fit_device(m, &fp);  // reads mean / var back together with the scalars
     } else {
-      rc = fit_device(m);
-      if (!rc) rc = predict_sharded(m, dZ, M, mean_out, var_out);
+      gpk_model* one = m;  // block-cyclic: fit + this rank's shard of the prediction pipelined behind the panels, slices all-gathered
+      rc = fit_predict_group(&one, 1, dZ, M, &mean_out, &var_out);
     }
   }
   if (dZ) dev_free(dZ, (size_t)M * d * 8);
@@ -649,9 +683,9 @@ int gpk_bench_posterior(const double* X, const double* y, int N, int d, const do
           rc = fit_device(m, &fp);  // includes the read-back of nlml, mean and variance (one synchronisation)
           if (rc) break;
         } else {
-          rc = fit_device(m);
-          if (rc) break;
-          rc = predict_sharded(m, dZ, M, hm.data(), hv.data());  // sharded over ranks, includes the read-back
+          gpk_model* one = m;
+          double *pm = hm.data(), *pv = hv.data();
+          rc = fit_predict_group(&one, 1, dZ, M, &pm, &pv);  // sharded over ranks, substitutions behind the panel events, includes the read-back
           if (rc) break;
         }
       }

@@ -89,6 +89,7 @@ extern "C" int gpk_class_laplace(gpk_model* m, const double* y, int link, double
     GPK_HIP(hipMemcpyAsync(&ferr, st.dscal, 8, hipMemcpyDeviceToHost, s));
     GPK_HIP(hipMemcpyAsync(&binfo, st.mb->dinfo, 4, hipMemcpyDeviceToHost, s));
     GPK_HIP(hipStreamSynchronize(s));
+    GPK_TRY(info_timeout_rc(binfo));
     if (binfo > 0) return gpk_set_err(-4, "Newton system lost positive definiteness (minor %d)", binfo);
     std::swap(st.df, st.dfn);
     iters = it + 1;
@@ -149,6 +150,7 @@ extern "C" int gpk_class_predict(gpk_model* m, const double* y, int link, const 
   GPK_HIP(hipMemcpyAsync(var_out, dvar, (size_t)M * 8, hipMemcpyDeviceToHost, s));
   if (prob_out) GPK_HIP(hipMemcpyAsync(prob_out, dprob, (size_t)M * 8, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipStreamSynchronize(s));
+  GPK_TRY(info_timeout_rc(binfo));
   if (binfo > 0) return gpk_set_err(-4, "gpk_class_predict: B lost positive definiteness (minor %d)", binfo);
   return 0;
 }

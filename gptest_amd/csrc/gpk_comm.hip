@@ -57,14 +57,9 @@ int gpk_comm_init(int rank, int nranks, const void* uid128) {
   G.nccl = c;
   G.rank = rank;
   G.nranks = nranks;
-  // The substitution stream is only used by the single-GPU pipeline, and an idle extra queue is not free on this part
-  // (gpk_init comment): a multi-rank process gives it up and gets the COMMUNICATION stream instead -- the panel
-  // broadcasts run there, off the panel chain (potrf_group), so it still has three: update, panel chain, communication.
-  if (G.s_pred && G.s_pred != G.s_panel) {
-    (void)hipStreamSynchronize(G.s_pred);
-    (void)hipStreamDestroy(G.s_pred);
-  }
-  G.s_pred = nullptr;
+  // A multi-rank process gets a COMMUNICATION stream on top of the three of the one-GPU layout: the panel broadcasts run there, off
+  // the panel chain (potrf_group).  The substitution stream stays (round 4): y and this rank's shard of the prediction are
+  // substituted on it behind the per-panel "available" events (fit_group_impl), as on one GPU.
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
   if (hipStreamCreateWithPriority(&G.s_comm, hipStreamNonBlocking, hi) != hipSuccess) {

@@ -65,6 +65,13 @@ struct Runtime {
   int corner_prio = 0;  // priority of the corner stream: 0 lowest, 1 that of the update stream, 2 highest
   int corner_hold = 0;  // no catch-up launch starts before the panel that begins at or after this column has been factored: the deferred work
                         // is held back until the factorisation turns chain-bound instead of competing with the bulk-bound first part
+  // tile pipeline: leaf + the two one-tile GEMMs of a step as ONE launch (potf2_chain_kernel) that polls a flag for the update
+  // stream's look-ahead update instead of waiting for an event in front of the launch.  -1: automatic (on where cross-stream flags
+  // work: flags_ok, probed by gpk_init -- they do not under a tool that serialises dispatches -- and never inside a graph capture)
+  int chain_fused = -1;
+  int flags_ok = 0;
+  bool capturing = false;
+  unsigned flag_epoch = 0;     // one value per tile-pipeline run: a stale flag of an earlier run never satisfies a wait
   int small_tile_below = 256;  // panel_update: launches with fewer 128x128 tiles than this use the 64x64-tile kernel
   // launch graphs (fit_device, option graphs): the whole multi-stream enqueue of one fit (+ fused prediction) captured once
   // per (shape, buffers, schedule) and replayed afterwards -- the reference's caller evaluates one shape hundreds of times
@@ -178,6 +185,8 @@ struct gpk_model {
   size_t hpin_doubles = 0;
   double* dws = nullptr;    // gemvT workspace 64*NB
   int* dinfo = nullptr;
+  unsigned* dflags = nullptr;  // three flags per tile column p (fused chain step): [p] the update stream has applied the look-ahead update of step p,
+                               // [nT + p] the chain kernel has written L(p,p) and Dinv(p), [2 nT + p] ... and L(p+1,p)
   SEParams se;
   double sn2 = 0, jitter = 0;
   double nlml = 0, logdet = 0, quad = 0;
@@ -191,6 +200,12 @@ struct gpk_model {
   double* Lpanel(int p) const { return dL + poff[p]; }
 };
 
+// *info of a factorisation read back on the host: > 0 is the first non-positive pivot (LAPACK style), GPK_INFO_TIMEOUT and above
+// means that a bounded device-side wait ran out (the fused chain step: k_potf2.hip) -- an error (-3), never a pivot.
+constexpr int GPK_INFO_TIMEOUT = 1 << 30;
+static inline int info_timeout_rc(int hinfo) {
+  return hinfo >= GPK_INFO_TIMEOUT ? gpk_set_err(-3, "a device-side wait of the factorisation timed out (results discarded)") : 0;
+}
 int model_create(gpk_model** out, int N, int d, bool keep_k, int P = -1, int r = -1, bool growable = false);
 void model_destroy(gpk_model* m);
 int decode_hyp(const double* log_hyp, int d, double jitter, gpk_model* m);
@@ -215,6 +230,9 @@ extern int g_potrf_corner[3];                                   // boundaries th
 int potrf_group(gpk_model* const* ms, int n);
 int fit_group(gpk_model* const* ms, int n);
 int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var);
+// fit + sharded prediction in one go: the y and prediction substitutions pipelined behind the per-panel events of the block-cyclic factorisation
+int fit_predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var);
+extern int g_dist_pipelined;        // 1 if the last block-cyclic fit queued its substitutions behind the panel events
 int build_K(gpk_model* m);                                      // dX -> dK (local block columns)
 int factor_panel(gpk_model* m, int p, hipStream_t s);          // owner only
 int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hipStream_t s);

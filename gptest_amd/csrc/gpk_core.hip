@@ -7,6 +7,8 @@
 Runtime G;
 int g_potrf_lookahead_used = 0;
 int g_potrf_tail_from = -1;  // first panel the last factorisation sent through the tile pipeline (-1: none)
+std::vector<int> g_last_pc0, g_last_pw;  // panel layout of the last single-GPU factorisation (gpk_get_option("last_panel_c0_<p>"): bench.py's phase split)
+int g_potrf_chain_fused = 0;  // steps of the last tile pipeline that ran as one launch (potf2_chain_kernel)
 extern "C" int gpk_comm_allreduce_max(double* inout, int n);
 static thread_local std::string g_err = "";
 
@@ -215,6 +217,8 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   m->dws_bytes = (size_t)64 * std::max(nb, G.nb_big) * 8;
   rc |= dev_alloc(reinterpret_cast<void**>(&m->dws), m->dws_bytes);
   rc |= dev_alloc_t(&m->dinfo, 4);
+  rc |= dev_alloc_t(&m->dflags, (size_t)3 * m->nT);
+  if (!rc && hipMemsetAsync(m->dflags, 0, (size_t)3 * m->nT * sizeof(unsigned), G.s_main) != hipSuccess) rc = gpk_set_err(-2, "memset failed");
   if (rc) {
     model_destroy(m);
     return -2;
@@ -229,6 +233,7 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
 void model_destroy(gpk_model* m) {
   if (!m) return;
   const size_t np = m->Npad;
+  dev_free(m->dflags, (size_t)3 * m->nT * sizeof(unsigned));
   dev_free(m->dinfo, 16);
   dev_free(m->dws, m->dws_bytes);
   dev_free(m->dse, sizeof(SEParams));
@@ -503,6 +508,7 @@ static int potrf_device_paired(gpk_model* m, const std::function<int(int)>* afte
 // panels, so the factor is bit-identical to it (tests).  `ev_prev_rest`: what plays REST(p_first - 1).
 // What was tried on top of this and dropped (a stream of its own for the full-height GEMMs, the two one-tile GEMMs in one
 // launch, flag-chained steps without event packets, a resident leaf server): DESIGN.md section 6.
+static int span_update(gpk_model* m, int o_first, int o_last, int r0g, int c0g, int ncols, int lower, hipStream_t s, int persist_grid);
 static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const std::function<int(int)>* after_panel) {
   hipStream_t sm = G.s_main, sc = G.s_panel;
   const int nP = m->nP, np_ = m->Npad;
@@ -511,7 +517,11 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
   hipEvent_t* ev_leaf = m->ev.data() + 3 * nP + 6;
   hipEvent_t* ev_tt = m->ev.data() + 4 * nP + 6;
   hipEvent_t* ev_near = m->ev.data() + 5 * nP + 6;
-  GPK_HIP(hipStreamWaitEvent(sm, ev_prev_rest, 0));
+  if (ev_prev_rest) GPK_HIP(hipStreamWaitEvent(sm, ev_prev_rest, 0));
+  // one launch per chain step (potf2_chain_kernel) where the full-tile leaf is used and cross-stream flags work
+  const bool fused_ok = (G.chain_fused > 0 || (G.chain_fused < 0 && G.flags_ok)) && !G.capturing && m->dflags;
+  const unsigned epoch = ++G.flag_epoch;
+  g_potrf_chain_fused = 0;
   for (int p = p_first; p < nP; ++p) {
     const int c0 = m->pc0[p], h = np_ - c0;
     const long ld = m->pld[p];
@@ -521,9 +531,22 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
     // ---- critical stream.  One event per step: `tt` after the two one-tile GEMMs (or `leaf` for the last tile, which has
     // none): an event packet on the chain stream costs ~5 us of a ~85 us step, and the full-height solve is never what the
     // chain waits for next (near(p) is due one leaf later).
+    const bool fused = fused_ok && h > 128 && h <= G.leaf_fat_rows;
+    // ... and the update stream's full-height solve / look-ahead update of this step do not wait for that launch to END: they poll
+    // the flags it raises after the leaf and after L(p+1,p) (chain_fused = 2; 1: they wait for the event behind the launch)
+    const bool early = fused && (G.chain_fused == 2 || G.chain_fused < 0);
+    if (fused) {
+      // leaf(p), L(p+1,p) and the update of tile (p+1,p+1) in one launch; the kernel itself waits (after the leaf) for the flag the
+      // update stream sets behind LAnear(p-1) -- the first step's row p+1 was brought up to date on this stream by the hand-over
+      GPK_TRY(launch_potf2_chain(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, p > p_first ? m->dflags + (p - 1) : nullptr, epoch, sc,
+                                 early ? m->dflags + m->nT + p : nullptr, early ? m->dflags + 2 * m->nT + p : nullptr));
+      GPK_HIP(hipEventRecord(ev_tt[p], sc));
+      ++g_potrf_chain_fused;
+    } else {
     GPK_TRY(leaf_launch(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, sc, h));
     if (h <= 128) GPK_HIP(hipEventRecord(ev_leaf[p], sc));
-    if (h > 128) {
+    }
+    if (h > 128 && !fused) {
       if (p > p_first) GPK_HIP(hipStreamWaitEvent(sc, ev_near[p - 1], 0));
       GemmNT t1{};  // L(p+1,p) = A(p+1,p) Dinv^T
       t1.A = Acol + (long)128 * ldk; t1.lda = ldk;
@@ -547,27 +570,38 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       GPK_HIP(hipEventRecord(ev_tt[p], sc));
     }
     // ---- full-height panel GEMMs, in front of the bulk on the update stream
-    GPK_HIP(hipStreamWaitEvent(sm, h <= 128 ? ev_leaf[p] : ev_tt[p], 0));
+    if (!early) GPK_HIP(hipStreamWaitEvent(sm, h <= 128 ? ev_leaf[p] : ev_tt[p], 0));
     if (h > 256) {
       GemmNT g{};  // SOLVE(p): rows from tile p+2
       g.A = Acol + (long)256 * ldk; g.lda = ldk;
       g.B = Dt; g.ldb = 128;
       g.C = Lp + (long)256 * ld; g.ldc = ld;
       g.m = h - 256; g.n = 128; g.k = 128; g.sub = 0;
+      if (early) { g.wait_flag = m->dflags + m->nT + p; g.wait_val = epoch; g.wait_info = m->dinfo; }
       GPK_TRY(launch_gemm_nt(g, false, sm));
     }
-    GPK_HIP(hipEventRecord(ev_panel[p], sm));  // every row of panel p is in place
-    if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sm));
-    if (after_panel) GPK_TRY((*after_panel)(p));
+    if (early && h <= 256) GPK_HIP(hipStreamWaitEvent(sm, ev_tt[p], 0));  // (no polling launch in this step: the event after all)
+    // every row of panel p is in place (early: not before the look-ahead update below, which is what has waited for L(p+1,p))
+    auto panel_done = [&]() -> int {
+      GPK_HIP(hipEventRecord(ev_panel[p], sm));
+      if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sm));
+      if (after_panel) GPK_TRY((*after_panel)(p));
+      return 0;
+    };
+    const bool late_panel_event = early && h > 256;
+    if (!late_panel_event) GPK_TRY(panel_done());
     if (h > 256) {
       GemmNT g{};  // LAnear(p): tile columns p+1, p+2, rows from tile p+2
       g.A = Lp + (long)256 * ld; g.lda = ld;
       g.B = Lp + (long)128 * ld; g.ldb = ld;
       g.C = Acol + (long)256 * ldk + 128; g.ldc = ldk;
       g.m = h - 256; g.n = std::min(256, h - 128); g.k = 128; g.sub = 1;
+      if (early) { g.wait_flag = m->dflags + 2 * m->nT + p; g.wait_val = epoch; g.wait_info = m->dinfo; }
       GPK_TRY(launch_gemm_nt(g, false, sm));
     }
+    if (late_panel_event) GPK_TRY(panel_done());
     GPK_HIP(hipEventRecord(ev_near[p], sm));
+    if (fused_ok && h > 256) GPK_TRY(launch_flag_set(m->dflags + p, epoch, sm));  // what the fused step p+1 polls
     if (h > 384) {
       GemmNT g{};  // LAfar(p): tile column p+3, rows from tile p+3
       g.A = Lp + (long)384 * ld; g.lda = ld;
@@ -680,7 +714,7 @@ static std::vector<CornerRegion> corner_plan(const gpk_model* m) {
 }
 // C[r0g:, c0g : c0g + ncols] -= sum over outer panels o in [o_first, o_last] of Lo[(r0g - oc0):, :] Lo[(c0g - oc0) : +ncols, :]^T, in
 // panel order, as ONE launch of the 8-wave kernel over a K-segment table (one panel: the plain update, any tile size)
-static int span_update(gpk_model* m, int o_first, int o_last, int r0g, int c0g, int ncols, int lower, hipStream_t s, int persist_grid = 0) {
+static int span_update(gpk_model* m, int o_first, int o_last, int r0g, int c0g, int ncols, int lower, hipStream_t s, int persist_grid) {
   if (o_first == o_last && persist_grid <= 0) return outer_update(m, o_last, r0g, c0g, ncols, lower, s);
   const int rows = m->Npad - r0g;
   if (rows <= 0 || ncols <= 0) return 0;
@@ -723,6 +757,8 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   }
   GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
   const int nP = m->nP;
+  g_last_pc0 = m->pc0;
+  g_last_pw = m->pw;
   g_potrf_lookahead_used = 0;
   if (!G.lookahead || nP < 3) {
     for (int p = 0; p < nP; ++p) {
@@ -775,7 +811,7 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
   const int o_tail = tail_first_panel(m);  // outer panels from here on go through the tile pipeline
   g_potrf_tail_from = (o_tail < nO) ? m->ofirst[o_tail] : -1;
-  if (o_tail == 0) return potrf_tail(m, 0, ev_start, after_panel);
+  if (o_tail == 0) return potrf_tail(m, 0, nullptr, after_panel);
   // Lazy corner (Runtime::corner_from): a panel in front of a boundary b updates columns < b only; the region behind the boundary
   // gets the updates of all panels in front of it from catch-up launches on the corner stream (chunks of panels, in order), the
   // last few of them together with the update of the boundary panel, the first one that needs the region up to date.  Up to
@@ -812,7 +848,7 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
         timer_end("trailing", sc);
         hipEvent_t e = m->ev[rg.ev_base + rg.next_chunk];
         GPK_HIP(hipEventRecord(e, sc));
-        if (G.stamps && G.dstamps && &rg == &regs[0] && rg.next_chunk < 64) GPK_TRY(launch_stamp(G.dstamps + 448 + rg.next_chunk, sc));
+        if (G.stamps && G.dstamps && &rg == &regs[0] && rg.next_chunk < 63) GPK_TRY(launch_stamp(G.dstamps + 448 + rg.next_chunk, sc));
         rg.ev_last = e;
         ++rg.next_chunk;
       }
@@ -822,21 +858,22 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
       // after it, so the chain stream applies this panel to three tile columns, the update stream to the rest
       // (which then stands for REST(first tail panel - 1))
       const int w_la = std::min(384, np_ - r0);
+      hipStream_t srest = sm;
       if (o > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[o - 1], 0));
       if (ev_bd) GPK_HIP(hipStreamWaitEvent(sp, ev_bd, 0));
-      GPK_TRY(span_update(m, pf, o, r0, r0, w_la, 1, sp));
-      GPK_HIP(hipStreamWaitEvent(sm, ev_panel[m->oend[o] - 1], 0));
-      if (ev_bd) GPK_HIP(hipStreamWaitEvent(sm, ev_bd, 0));
+      GPK_TRY(span_update(m, pf, o, r0, r0, w_la, 1, sp, 0));
+      GPK_HIP(hipStreamWaitEvent(srest, ev_panel[m->oend[o] - 1], 0));
+      if (ev_bd) GPK_HIP(hipStreamWaitEvent(srest, ev_bd, 0));
       const int r1 = r0 + w_la;
       if (np_ - r1 > 0) {
         const long nt = (np_ - r1) / 128;
         const char* tname = (nt * (nt + 1) / 2 < G.small_tile_below) ? "trailing_small" : "trailing";
-        timer_begin(tname, sm, (double)(np_ - r1) * (np_ - r1) * kspan);
-        GPK_TRY(span_update(m, pf, o, r1, r1, np_ - r1, 1, sm));
-        timer_end(tname, sm);
+        timer_begin(tname, srest, (double)(np_ - r1) * (np_ - r1) * kspan);
+        GPK_TRY(span_update(m, pf, o, r1, r1, np_ - r1, 1, srest, 0));
+        timer_end(tname, srest);
       }
-      GPK_HIP(hipEventRecord(ev_trail[o], sm));
-      return potrf_tail(m, m->ofirst[o_tail], ev_trail[o], after_panel);
+      GPK_HIP(hipEventRecord(ev_trail[o], srest));
+      return potrf_tail(m, m->ofirst[o_tail], nullptr, after_panel);  // (the hand-over's rest update sits in front of the tail's launches on the update stream: stream order)
     }
     const int wn = (o + 1 < nO) ? m->ow[o + 1] : 0;  // width of the next block column
     const int w1 = (o + 1 < nO) ? m->pw[m->ofirst[o + 1]] : 0;  // ... of its first inner panel: the look-ahead column
@@ -844,7 +881,7 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
       // (a) s_panel: the look-ahead column gets outer panel o's update (lower trapezoid) ...
       if (o > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[o - 1], 0));  // earlier updates of that column
       if (ev_bd) GPK_HIP(hipStreamWaitEvent(sp, ev_bd, 0));  // ... those of the region's catch-up launches
-      GPK_TRY(span_update(m, pf, o, r0, r0, w1, 1, sp));
+      GPK_TRY(span_update(m, pf, o, r0, r0, w1, 1, sp, 0));
     }
     GPK_HIP(hipStreamWaitEvent(sm, ev_panel[m->oend[o] - 1], 0));
     if (ev_bd) GPK_HIP(hipStreamWaitEvent(sm, ev_bd, 0));
@@ -867,7 +904,7 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
       // tail that outer_update routes to the 64x64-tile kernel is timed under its own name
       const double mm = (double)(np_ - r1), below = (double)(np_ - ccap);
       timer_begin(tname, sm, (mm * mm - below * below) * kspan);
-      GPK_TRY(span_update(m, pf, o, r1, r1, ccap - r1, 1, sm));
+      GPK_TRY(span_update(m, pf, o, r1, r1, ccap - r1, 1, sm, 0));
       timer_end(tname, sm);
     }
     GPK_HIP(hipEventRecord(ev_trail[o], sm));
@@ -1112,7 +1149,19 @@ static int predict_step(gpk_model* m, int p, int Mpad, double* dR, double* dV, h
 
 // Block-cyclic fit of the rank models living in this process (see potrf_group): every rank builds its block columns
 // of K, the group factors, every rank then holds all of L and runs the y substitution redundantly.
-int fit_group(gpk_model* const* ms, int n) {
+// gp (optional): a sharded prediction fused into the fit -- rank r solves the test points [r Mc, (r+1) Mc) into gp->bufs[i].
+// Where the look-ahead schedule runs and the process has a substitution stream, the forward substitutions (y on every rank, the
+// rank's rows of Kzx) are queued on it behind the per-panel "available on this rank" events of the factorisation (the owner: its
+// own factorisation, everybody else: the broadcast), as fit_device does on one GPU: they fill the chain- and link-bound stretches
+// of the block-cyclic factorisation instead of following it (2 nP dependent launches for y alone: 1.3 ms at N = 16384).
+struct GroupPredict {
+  const double* dZ = nullptr;
+  int M = 0, Mc = 0, Mpad = 0;          // all test points, per rank, per rank padded
+  struct Bufs { double *dR = nullptr, *dV = nullptr, *dall = nullptr; };
+  std::vector<Bufs> bufs;               // one per local model
+};
+int g_dist_pipelined = 0;  // 1 if the last block-cyclic fit queued its substitutions behind the panel events
+static int fit_group_impl(gpk_model* const* ms, int n, const GroupPredict* gp) {
   hipStream_t s = G.s_main;
   for (int i = 0; i < n; ++i) {
     gpk_model* m = ms[i];
@@ -1123,16 +1172,48 @@ int fit_group(gpk_model* const* ms, int n) {
   timer_begin("potrf", s);
   GPK_TRY(potrf_group(ms, n));
   timer_end("potrf", s);
+  hipStream_t sq = G.s_pred;
+  const bool pipelined = sq && G.fuse_predict && g_dist_lookahead_used;  // (virtual ranks: the stand-in broadcasts share this stream -- queued first, so the substitutions follow them)
+  g_dist_pipelined = pipelined ? 1 : 0;
   for (int i = 0; i < n; ++i) {
     gpk_model* m = ms[i];
+    const int np_ = m->Npad;
     GPK_TRY(launch_sum_log_diag(m->dDinv, m->N, m->dscal + 0, s));
+    const int m0 = gp ? ((m->P > 1) ? m->r * gp->Mc : 0) : 0;
+    const int cnt = gp ? std::max(0, std::min(gp->Mc, gp->M - m0)) : 0;
+    const int mp = round_up(std::max(cnt, 1), 128);
+    if (gp) GPK_HIP(hipMemsetAsync(m->shard_loc, 0, (size_t)2 * gp->Mpad * 8, s));
+    if (pipelined && (m->has_y || cnt > 0)) {
+      // everything below only needs panels <= p on THIS rank: m->ev[p] (dist_publish_panel); m->ev[2 nP] = the K build is done
+      hipEvent_t* ev_avail = m->ev.data();
+      GPK_HIP(hipStreamWaitEvent(sq, m->ev[2 * m->nP], 0));
+      if (m->has_y) GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, sq));
+      if (cnt > 0) GPK_TRY(launch_se_build(gp->dZ + (size_t)m0 * m->d, cnt, mp, m->dX, m->N, np_, m->se, 0, 0, gp->bufs[i].dR, np_, 0, sq));
+      for (int p = 0; p < m->nP; ++p) {
+        const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
+        GPK_HIP(hipStreamWaitEvent(sq, ev_avail[p], 0));
+        if (m->has_y) {
+          double* Lp = m->Lpanel(p);
+          GPK_TRY(launch_diag_solve(Lp, w, m->pld[p], m->dDinv + (long)(c0 / 128) * 128 * 128, m->dw + c0, 0, sq));
+          GPK_TRY(launch_gemv_sub(Lp + (long)w * m->pld[p], m->pld[p], h - w, w, m->dw + c0, m->dw + c0 + w, sq));
+        }
+        if (cnt > 0) GPK_TRY(predict_step(m, p, mp, gp->bufs[i].dR, gp->bufs[i].dV, sq, nullptr));
+      }
+      hipEvent_t ev_pd = m->ev[2 * m->nP + 3];
+      GPK_HIP(hipEventRecord(ev_pd, sq));
+      GPK_HIP(hipStreamWaitEvent(s, ev_pd, 0));
+      if (m->has_y) GPK_TRY(launch_dot(m->dw, m->dw, np_, m->dscal + 1, s));
+      if (cnt > 0) GPK_TRY(launch_row_stats(gp->bufs[i].dV, np_, cnt, np_, m->dw, m->se.sf2, m->shard_loc, m->shard_loc + gp->Mpad, s));
+      continue;
+    }
     if (m->has_y) {
       timer_begin("solve_y", s);
-      GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)m->Npad * 8, hipMemcpyDeviceToDevice, s));
+      GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, s));
       GPK_TRY(trsv_forward(m, m->dw));
-      GPK_TRY(launch_dot(m->dw, m->dw, m->Npad, m->dscal + 1, s));
+      GPK_TRY(launch_dot(m->dw, m->dw, np_, m->dscal + 1, s));
       timer_end("solve_y", s);
     }
+    if (cnt > 0) GPK_TRY(predict_device(m, gp->dZ + (size_t)m0 * m->d, cnt, mp, gp->bufs[i].dR, gp->bufs[i].dV, m->shard_loc, m->shard_loc + gp->Mpad));
   }
   std::vector<double> hs((size_t)2 * n, 0.0);
   std::vector<int> hinfo(n, 0);
@@ -1145,8 +1226,10 @@ int fit_group(gpk_model* const* ms, int n) {
   // well (on what the identity factors of the failed tile left them): the verdict is the FIRST failing minor over all
   // ranks, as LAPACK reports it -- the smallest positive info, found with the max-reduction as the largest 2^30 - info.
   int worst = 0;
-  for (int i = 0; i < n; ++i)
+  for (int i = 0; i < n; ++i) {
+    GPK_TRY(info_timeout_rc(hinfo[i]));
     if (hinfo[i] > 0 && (worst == 0 || hinfo[i] < worst)) worst = hinfo[i];
+  }
   if (!ms[0]->virtual_rank && ms[0]->P > 1) {
     double hi = worst > 0 ? (double)((1 << 30) - worst) : 0.0;
     GPK_TRY(gpk_comm_allreduce_max(&hi, 1));
@@ -1164,6 +1247,7 @@ int fit_group(gpk_model* const* ms, int n) {
   if (worst > 0) return worst > ms[0]->N ? ms[0]->N : worst;
   return 0;
 }
+int fit_group(gpk_model* const* ms, int n) { return fit_group_impl(ms, n, nullptr); }
 
 // Everything one fit queues on the three streams, from the K build to the read-back into the model's pinned staging
 // buffer -- no synchronisation, no allocation of device memory: the body fit_device either runs eagerly or captures into
@@ -1172,6 +1256,10 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp, const SEParams* dse
   hipStream_t s = G.s_main;
   const int np_ = m->Npad;
   const double* sf2_dev = dse ? &dse->sf2 : nullptr;
+  if (G.stamps && G.dstamps) {
+    GPK_HIP(hipMemsetAsync(G.dstamps, 0, 1024 * 8, s));
+    GPK_TRY(launch_stamp(G.dstamps + 447, s));  // "stamp_start": the fit begins (before the K build)
+  }
   timer_begin("kbuild", s, (m->keep_k ? 8.0 : 4.0) * np_ * np_ + 8.0 * m->N * m->d);
   GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s, 0, nullptr, dse));
   timer_end("kbuild", s);
@@ -1223,7 +1311,6 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp, const SEParams* dse
       GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq, 0, nullptr, dse));
     }
   }
-  if (G.stamps && G.dstamps) GPK_HIP(hipMemsetAsync(G.dstamps, 0, 1024 * 8, s));
   const auto host_t0 = std::chrono::steady_clock::now();
   GPK_TRY(potrf_device(m));
   G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
@@ -1306,7 +1393,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     }
     m->hpin_doubles = need;
   }
-  if (G.stamps && !G.dstamps && m->nP <= 448) {
+  if (G.stamps && !G.dstamps && m->nP <= 447) {
     GPK_HIP(hipMalloc((void**)&G.dstamps, 1024 * 8));
     G.hstamps.assign(1024, 0);
   }
@@ -1341,7 +1428,9 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
       hipGraphExec_t exec = nullptr;
       hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
       if (ce == hipSuccess) {
+        G.capturing = true;  // (a captured enqueue uses events only: a graph gives no launch-order guarantee a polling kernel could rely on)
         const int erc = fit_enqueue(m, fp, m->dse);
+        G.capturing = false;
         ce = hipStreamEndCapture(s, &graph);
         if (erc != 0) {
           G.graph_fallback = std::string("enqueue failed during capture: ") + gpk_err_cstr();
@@ -1402,6 +1491,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
   if (fp && fp->h_mean) std::memcpy(fp->h_mean, m->hpin + 4, (size_t)fp->M * 8);
   if (fp && fp->h_var) std::memcpy(fp->h_var, m->hpin + 4 + fp->M, (size_t)fp->M * 8);
   m->info = hinfo;
+  GPK_TRY(info_timeout_rc(hinfo));
   if (hinfo > 0) return hinfo > m->N ? m->N : hinfo;
   m->factored = true;
   m->logdet = m->hpin[0];
@@ -1501,8 +1591,10 @@ static int predict_step(gpk_model* m, int p, int Mpad, double* dR, double* dV, h
   return 0;
 }
 
+int g_pred_defer_col = 0;  // boundary the last fused prediction deferred its far updates to (0: none)
 static std::shared_ptr<PredDefer> predict_defer_make(const gpk_model* m) {
   const int b = predict_defer_col(m);
+  g_pred_defer_col = b > 0 ? b : 0;
   if (b <= 0) return nullptr;
   auto d = std::make_shared<PredDefer>();
   d->b = b;
@@ -1697,68 +1789,101 @@ int nlml_grad_device(gpk_model* m, double* h_grad) {
 // M test points sharded over the P ranks of a block-cyclic model (every rank holds all of L): rank q solves the
 // points [q Mc, (q+1) Mc), the [mean | var] slices are all-gathered.  ms[0..n) as in potrf_group; every local rank
 // writes the gathered result to its own h_mean[i] / h_var[i].
-int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var) {
-  hipStream_t s = G.s_main;
+static int group_predict_alloc(gpk_model* const* ms, int n, const double* dZ, int M, GroupPredict* gp) {
   if (n < 1 || !ms || !ms[0]) return gpk_set_err(-1, "predict_group: empty group");
-  const int P = ms[0]->P, d = ms[0]->d;
+  const int P = ms[0]->P;
   if (n > 1 && n != P) return gpk_set_err(-1, "predict_group: a group of %d needs the %d virtual ranks", n, P);
-  const int Mc = (M + P - 1) / P;  // test points per rank
-  const int Mpad = round_up(Mc, 128);
-  const size_t szR = (size_t)Mpad * ms[0]->Npad, slice = (size_t)2 * Mpad;
-  struct Bufs { double *dR = nullptr, *dV = nullptr, *dall = nullptr; };
-  std::vector<Bufs> bufs(n);
-  std::vector<std::vector<double>> hall(n, std::vector<double>(slice * P));
+  gp->dZ = dZ;
+  gp->M = M;
+  gp->Mc = (M + P - 1) / P;  // test points per rank
+  gp->Mpad = round_up(gp->Mc, 128);
+  gp->bufs.assign(n, GroupPredict::Bufs());
+  const size_t szR = (size_t)gp->Mpad * ms[0]->Npad, slice = (size_t)2 * gp->Mpad;
   int rc = 0;
   for (int i = 0; i < n && !rc; ++i) {
-    rc |= dev_alloc_t(&bufs[i].dR, szR);
-    rc |= dev_alloc_t(&bufs[i].dV, szR);
+    rc |= dev_alloc_t(&gp->bufs[i].dR, szR);
+    rc |= dev_alloc_t(&gp->bufs[i].dV, szR);
     rc |= dev_alloc_t(&ms[i]->shard_loc, slice);
-    rc |= dev_alloc_t(&bufs[i].dall, slice * P);
+    rc |= dev_alloc_t(&gp->bufs[i].dall, slice * P);
   }
-  auto body = [&]() -> int {
-    for (int i = 0; i < n; ++i) {  // local solve of this rank's slice
-      gpk_model* m = ms[i];
-      const int m0 = (P > 1) ? m->r * Mc : 0;
-      const int cnt = std::max(0, std::min(Mc, M - m0));
-      GPK_HIP(hipMemsetAsync(m->shard_loc, 0, slice * 8, s));
-      if (cnt > 0)
-        GPK_TRY(predict_device(m, dZ + (size_t)m0 * d, cnt, round_up(cnt, 128), bufs[i].dR, bufs[i].dV, m->shard_loc,
-                               m->shard_loc + Mpad));
-    }
-    for (int i = 0; i < n; ++i) {  // all-gather of the slices
-      gpk_model* m = ms[i];
-      if (P == 1) {
-        GPK_HIP(hipMemcpyAsync(bufs[i].dall, m->shard_loc, slice * 8, hipMemcpyDeviceToDevice, s));
-      } else if (m->virtual_rank) {
-        if (!m->vgroup) return gpk_set_err(-1, "internal: virtual rank %d without a group", m->r);
-        for (int q = 0; q < P; ++q)
-          GPK_HIP(hipMemcpyAsync(bufs[i].dall + slice * q, m->vgroup[q]->shard_loc, slice * 8, hipMemcpyDeviceToDevice, s));
-      } else {
-        GPK_TRY(comm_allgather(m->shard_loc, bufs[i].dall, slice, s));
-      }
-      GPK_HIP(hipMemcpyAsync(hall[i].data(), bufs[i].dall, slice * P * 8, hipMemcpyDeviceToHost, s));
-    }
-    if (hipStreamSynchronize(s) != hipSuccess) return gpk_set_err(-2, "predict: %s", hipGetErrorString(hipGetLastError()));
-    for (int i = 0; i < n; ++i)
-      for (int q = 0; q < P; ++q) {
-        const int q0 = q * Mc;
-        const int qc = std::min(Mc, M - q0);
-        for (int j = 0; j < qc; ++j) {
-          h_mean[i][q0 + j] = hall[i][slice * q + j];
-          h_var[i][q0 + j] = hall[i][slice * q + Mpad + j];
-        }
-      }
-    return 0;
-  };
-  if (!rc) rc = body();
-  if (rc) (void)hipStreamSynchronize(s);
-  for (int i = 0; i < n; ++i) {
-    if (bufs[i].dR) dev_free(bufs[i].dR, szR * 8);
-    if (bufs[i].dV) dev_free(bufs[i].dV, szR * 8);
-    if (bufs[i].dall) dev_free(bufs[i].dall, slice * P * 8);
+  return rc;
+}
+static void group_predict_free(gpk_model* const* ms, int n, GroupPredict* gp) {
+  const int P = ms[0]->P;
+  const size_t szR = (size_t)gp->Mpad * ms[0]->Npad, slice = (size_t)2 * gp->Mpad;
+  for (int i = 0; i < n && i < (int)gp->bufs.size(); ++i) {
+    if (gp->bufs[i].dR) dev_free(gp->bufs[i].dR, szR * 8);
+    if (gp->bufs[i].dV) dev_free(gp->bufs[i].dV, szR * 8);
+    if (gp->bufs[i].dall) dev_free(gp->bufs[i].dall, slice * P * 8);
     if (ms[i]->shard_loc) dev_free(ms[i]->shard_loc, slice * 8);
     ms[i]->shard_loc = nullptr;
   }
+}
+// all-gather of the per-rank [mean | var] slices (m->shard_loc, filled on s_main) and read-back into every local rank's host arrays
+static int group_predict_gather(gpk_model* const* ms, int n, GroupPredict* gp, double* const* h_mean, double* const* h_var) {
+  hipStream_t s = G.s_main;
+  const int P = ms[0]->P, M = gp->M, Mc = gp->Mc, Mpad = gp->Mpad;
+  const size_t slice = (size_t)2 * Mpad;
+  std::vector<std::vector<double>> hall(n, std::vector<double>(slice * P));
+  for (int i = 0; i < n; ++i) {
+    gpk_model* m = ms[i];
+    if (P == 1) {
+      GPK_HIP(hipMemcpyAsync(gp->bufs[i].dall, m->shard_loc, slice * 8, hipMemcpyDeviceToDevice, s));
+    } else if (m->virtual_rank) {
+      if (!m->vgroup) return gpk_set_err(-1, "internal: virtual rank %d without a group", m->r);
+      for (int q = 0; q < P; ++q)
+        GPK_HIP(hipMemcpyAsync(gp->bufs[i].dall + slice * q, m->vgroup[q]->shard_loc, slice * 8, hipMemcpyDeviceToDevice, s));
+    } else {
+      GPK_TRY(comm_allgather(m->shard_loc, gp->bufs[i].dall, slice, s));
+    }
+    GPK_HIP(hipMemcpyAsync(hall[i].data(), gp->bufs[i].dall, slice * P * 8, hipMemcpyDeviceToHost, s));
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) return gpk_set_err(-2, "predict: %s", hipGetErrorString(hipGetLastError()));
+  for (int i = 0; i < n; ++i)
+    for (int q = 0; q < P; ++q) {
+      const int q0 = q * Mc;
+      const int qc = std::min(Mc, M - q0);
+      for (int j = 0; j < qc; ++j) {
+        h_mean[i][q0 + j] = hall[i][slice * q + j];
+        h_var[i][q0 + j] = hall[i][slice * q + Mpad + j];
+      }
+    }
+  return 0;
+}
+
+int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var) {
+  hipStream_t s = G.s_main;
+  GroupPredict gp;
+  int rc = group_predict_alloc(ms, n, dZ, M, &gp);
+  auto body = [&]() -> int {
+    const int P = ms[0]->P, d = ms[0]->d;
+    for (int i = 0; i < n; ++i) {  // local solve of this rank's slice
+      gpk_model* m = ms[i];
+      const int m0 = (P > 1) ? m->r * gp.Mc : 0;
+      const int cnt = std::max(0, std::min(gp.Mc, M - m0));
+      GPK_HIP(hipMemsetAsync(m->shard_loc, 0, (size_t)2 * gp.Mpad * 8, s));
+      if (cnt > 0)
+        GPK_TRY(predict_device(m, dZ + (size_t)m0 * d, cnt, round_up(cnt, 128), gp.bufs[i].dR, gp.bufs[i].dV, m->shard_loc,
+                               m->shard_loc + gp.Mpad));
+    }
+    return group_predict_gather(ms, n, &gp, h_mean, h_var);
+  };
+  if (!rc) rc = body();
+  if (rc) (void)hipStreamSynchronize(s);
+  if (n >= 1 && ms && ms[0]) group_predict_free(ms, n, &gp);
+  return rc;
+}
+
+// fit + sharded prediction of a block-cyclic job in one go: the substitutions ride on the panel events (fit_group_impl), the slices
+// are gathered afterwards.  rc > 0: not positive definite (as fit_group).
+int fit_predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var) {
+  hipStream_t s = G.s_main;
+  GroupPredict gp;
+  int rc = group_predict_alloc(ms, n, dZ, M, &gp);
+  if (!rc) rc = fit_group_impl(ms, n, &gp);
+  if (!rc) rc = group_predict_gather(ms, n, &gp, h_mean, h_var);
+  if (rc) (void)hipStreamSynchronize(s);
+  if (n >= 1 && ms && ms[0]) group_predict_free(ms, n, &gp);
   return rc;
 }
 

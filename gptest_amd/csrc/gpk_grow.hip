@@ -108,6 +108,7 @@ extern "C" int gpk_append(gpk_model** handle_inout, const double* X_new, const d
     GPK_HIP(hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s));
     GPK_HIP(hipStreamSynchronize(s));
     m->info = hinfo;
+    GPK_TRY(info_timeout_rc(hinfo));
     if (hinfo > 0) {
       m->factored = false;
       return gpk_set_err(hinfo > n_new ? n_new : hinfo, "kernel matrix is not positive definite after the append (leading minor %d)", hinfo);

@@ -6,6 +6,7 @@
 #include "gpk_core.h"
 #include <cmath>
 #include <map>
+#include <chrono>
 #include <rccl/rccl.h>
 
 const char* gpk_err_cstr();
@@ -45,6 +46,7 @@ static int virtual_job_check_info(VirtualJob& job, int N) {
     int hinfo = 0;
     GPK_HIP(hipMemcpyAsync(&hinfo, m->dinfo, 4, hipMemcpyDeviceToHost, s));
     GPK_HIP(hipStreamSynchronize(s));
+    GPK_TRY(info_timeout_rc(hinfo));
     if (hinfo > worst) worst = hinfo;
   }
   if (worst > 0) return worst > N ? N : worst;
@@ -154,6 +156,55 @@ int gpk_test_gemm_segs(const double* A, const double* B, double* C, int m, int n
   return 0;
 }
 
+// One chain step of the tile pipeline on a 256 x 256 block B (lower tiles (0,0), (1,0), (1,1) used): leaf of tile (0,0), L(1,0) = B(1,0)
+// Dinv^T, B(1,1) -= L(1,0) L(1,0)^T.  mode 0: the three launches (full-tile leaf, two one-tile GEMMs); 1: potf2_chain_kernel without a
+// flag; 2: with a flag that the update stream sets while the kernel is running; 3: with a flag nobody sets (the bounded wait must
+// give up: returns -3).  L_out 256 x 128 (rows of L(0,0), then of L(1,0)), Dinv_out 128 x 128, A11_out 128 x 128.  Returns info.
+int gpk_test_chain_step(const double* B, double* L_out, double* Dinv_out, double* A11_out, int mode) {
+  GPK_TRY(rt_require());
+  if (!B || !L_out || !Dinv_out || !A11_out || mode < 0 || mode > 3) return gpk_set_err(-1, "gpk_test_chain_step: bad arguments");
+  hipStream_t sm = G.s_main, sc = G.s_panel;
+  Scratch scr;
+  double *dB = nullptr, *dL = nullptr, *dD = nullptr, *junk = nullptr;
+  int* dinfo = nullptr;
+  unsigned* dflag = nullptr;
+  GPK_TRY(scr.get(&dB, (size_t)256 * 256));
+  GPK_TRY(scr.get(&dL, (size_t)256 * 128));
+  GPK_TRY(scr.get(&dD, (size_t)128 * 128));
+  GPK_TRY(scr.get(&dinfo, (size_t)4));
+  GPK_TRY(scr.get(&dflag, (size_t)4));
+  GPK_TRY(scr.get(&junk, (size_t)1 << 22));
+  GPK_HIP(hipMemcpyAsync(dB, B, (size_t)256 * 256 * 8, hipMemcpyHostToDevice, sm));
+  GPK_HIP(hipMemsetAsync(dinfo, 0, 16, sm));
+  GPK_HIP(hipMemsetAsync(dflag, 0, 16, sm));
+  GPK_HIP(hipStreamSynchronize(sm));
+  if (mode == 0) {
+    GPK_TRY(launch_potf2_trtri_128(dB, 256, dL, 128, dD, dinfo, 0, 0, sc, 1));
+    GemmNT t1{};
+    t1.A = dB + 128 * 256; t1.lda = 256; t1.B = dD; t1.ldb = 128; t1.C = dL + 128 * 128; t1.ldc = 128; t1.m = t1.n = t1.k = 128;
+    GPK_TRY(launch_gemm_tile128(t1, sc));
+    GemmNT t2{};
+    t2.A = dL + 128 * 128; t2.lda = 128; t2.B = t2.A; t2.ldb = 128; t2.C = dB + 128 * 256 + 128; t2.ldc = 256; t2.m = t2.n = t2.k = 128; t2.sub = 1; t2.lower = 1;
+    GPK_TRY(launch_gemm_tile128(t2, sc));
+  } else {
+    GPK_TRY(launch_potf2_chain(dB, 256, dL, 128, dD, dinfo, 0, mode == 1 ? nullptr : dflag, 7u, sc));
+    if (mode == 2) {  // the flag arrives from the other stream, behind some work, while the kernel runs
+      GPK_TRY(launch_fill(junk, (size_t)1 << 22, 1.0, sm));
+      GPK_TRY(launch_flag_set(dflag, 7u, sm));
+    }
+  }
+  GPK_HIP(hipStreamSynchronize(sc));
+  GPK_HIP(hipStreamSynchronize(sm));
+  int hinfo = 0;
+  GPK_HIP(hipMemcpy(&hinfo, dinfo, 4, hipMemcpyDeviceToHost));
+  GPK_HIP(hipMemcpy(L_out, dL, (size_t)256 * 128 * 8, hipMemcpyDeviceToHost));
+  GPK_HIP(hipMemcpy(Dinv_out, dD, (size_t)128 * 128 * 8, hipMemcpyDeviceToHost));
+  GPK_HIP(hipMemcpy2DAsync(A11_out, 128 * 8, dB + 128 * 256 + 128, 256 * 8, 128 * 8, 128, hipMemcpyDeviceToHost, sm));
+  GPK_HIP(hipStreamSynchronize(sm));
+  GPK_TRY(info_timeout_rc(hinfo));
+  return hinfo;
+}
+
 int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out, int full_tile) {
   GPK_TRY(rt_require());
   hipStream_t s = G.s_main;
@@ -222,14 +273,21 @@ extern "C" int gpk_test_dist_posterior(const double* X, const double* y, int N, 
       GPK_HIP(hipMemsetAsync(m->dy, 0, (size_t)m->Npad * 8, s));
       GPK_HIP(hipMemcpyAsync(m->dy, y, (size_t)N * 8, hipMemcpyHostToDevice, s));
     }
-    GPK_TRY(fit_group(job.ms.data(), P));
     std::vector<double*> hm(P), hv(P);
     for (int r = 0; r < P; ++r) {
-      nlml_out[r] = job.ms[r]->nlml;
       hm[r] = mean_out + (size_t)r * M;
       hv[r] = var_out + (size_t)r * M;
     }
-    return predict_group(job.ms.data(), P, dZ, M, hm.data(), hv.data());
+    // option fuse_predict (default): fit + sharded prediction in one go, the substitutions behind the panel events -- what
+    // gpk_fit_predict / gpk_bench_posterior run on a real rank; 0: fit, then the separate sharded prediction (gpk_fit + gpk_predict)
+    if (G.fuse_predict) {
+      GPK_TRY(fit_predict_group(job.ms.data(), P, dZ, M, hm.data(), hv.data()));
+    } else {
+      GPK_TRY(fit_group(job.ms.data(), P));
+      GPK_TRY(predict_group(job.ms.data(), P, dZ, M, hm.data(), hv.data()));
+    }
+    for (int r = 0; r < P; ++r) nlml_out[r] = job.ms[r]->nlml;
+    return 0;
   };
   int rc = body();
   if (rc) (void)hipStreamSynchronize(s);
@@ -267,6 +325,49 @@ __global__ __launch_bounds__(256) void lds_bank_probe_kernel(double* out, int re
 }
 
 extern "C" {
+
+// How many streams run kernels truly side by side?  nstreams streams (priority of stream i: bit i of high_mask -> highest, else normal;
+// bit i of low_mask -> lowest) each get `reps` launches of a small spinning kernel (wgs workgroups, ~us_each microseconds), queued round
+// robin; out_us[i] = time per launch on stream i, out_us[nstreams] = wall time of everything per launch-round.
+__global__ void spin_kernel(unsigned long long ticks, unsigned* sink) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(2);
+  if (sink && threadIdx.x == 0 && blockIdx.x == 0xffffffffu) *sink = 1;
+}
+int gpk_bench_streams(int nstreams, int high_mask, int low_mask, int wgs, int us_each, int reps, int use_lib_streams, double* out_us) {
+  GPK_TRY(rt_require());
+  if (nstreams < 1 || nstreams > 8 || reps < 1) return gpk_set_err(-1, "gpk_bench_streams: bad arguments");
+  int lo = 0, hi = 0;
+  GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  std::vector<hipStream_t> st(nstreams, nullptr);
+  std::vector<bool> own(nstreams, true);
+  hipStream_t lib[3] = {G.s_main, G.s_panel, G.s_pred};
+  for (int i = 0; i < nstreams; ++i) {
+    if (use_lib_streams && i < 3 && lib[i]) { st[i] = lib[i]; own[i] = false; continue; }
+    const int pr = (high_mask >> i) & 1 ? hi : ((low_mask >> i) & 1 ? lo : (lo + hi) / 2);
+    GPK_HIP(hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, pr));
+  }
+  std::vector<hipEvent_t> e0(nstreams), e1(nstreams);
+  for (int i = 0; i < nstreams; ++i) { GPK_HIP(hipEventCreate(&e0[i])); GPK_HIP(hipEventCreate(&e1[i])); }
+  for (int i = 0; i < nstreams; ++i) hipLaunchKernelGGL(spin_kernel, dim3(wgs), dim3(256), 0, st[i], 100ull, nullptr);  // queues exist
+  GPK_HIP(hipDeviceSynchronize());
+  const auto w0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < nstreams; ++i) GPK_HIP(hipEventRecord(e0[i], st[i]));
+  for (int r = 0; r < reps; ++r)
+    for (int i = 0; i < nstreams; ++i) hipLaunchKernelGGL(spin_kernel, dim3(wgs), dim3(256), 0, st[i], (unsigned long long)us_each * 100ull, nullptr);
+  for (int i = 0; i < nstreams; ++i) GPK_HIP(hipEventRecord(e1[i], st[i]));
+  GPK_HIP(hipDeviceSynchronize());
+  out_us[nstreams] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count() / reps;
+  for (int i = 0; i < nstreams; ++i) {
+    float ms = 0;
+    GPK_HIP(hipEventElapsedTime(&ms, e0[i], e1[i]));
+    out_us[i] = 1e3 * ms / reps;
+    (void)hipEventDestroy(e0[i]);
+    (void)hipEventDestroy(e1[i]);
+    if (own[i]) (void)hipStreamDestroy(st[i]);
+  }
+  return 0;
+}
 
 int gpk_bench_lds_bank_probe(int pattern, int reps) {
   GPK_TRY(rt_require());

@@ -64,6 +64,9 @@ struct GemmNT {
   const unsigned* guest;  // the guest table (filled in by launch_gemm_nt; nullptr = do not poll)
   int prio;  // 64x64-tile kernel: raise the waves' issue priority (s_setprio): set by launch_gemm_nt for launches on the panel-chain stream
   unsigned long long* trace;  // timing builds only (make DBG=1): per-workgroup time stamps
+  // 64x64-tile kernel: every workgroup waits (bounded; a time-out poisons *wait_info) until *wait_flag has reached wait_val before
+  // it touches memory -- the launch can be resident and ready BEFORE its producer on another stream has finished (tile pipeline)
+  const unsigned* wait_flag; unsigned wait_val; int* wait_info;
 };
 // K-segment table of the 8-wave kernel: the K range of ONE update is the concatenation of up to GPK_MAXSEG separately stored
 // operand pairs (factored panels, each packed with its own leading dimension), applied in table order inside one MFMA chain
@@ -99,6 +102,18 @@ int launch_gemm_auto(const GemmNT& g, hipStream_t s);
 // its CU with nobody, instead of the slot-sized one (k_potf2.hip).  Same bits either way.
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info,
                            int col0, int n_valid, hipStream_t s, int fat = 0);
+
+// One launch per chain step of the tile pipeline (k_potf2.hip: potf2_chain_kernel): the full-tile leaf of tile (p,p) at A, then
+// L(p+1,p) = A(p+1,p) Dinv^T (written to L + 128 * ldl) and A(p+1,p+1) -= L(p+1,p) L(p+1,p)^T in place, bit for bit what the leaf and
+// two one-tile GEMMs produce.  flag != nullptr: rows p+1 are not touched before *flag has reached `want` (set by launch_flag_set
+// on the stream that updates them); the wait is bounded and poisons *info with GPK_INFO_TIMEOUT when it runs out.
+// done_leaf / done_t1 (optional): flags the kernel raises to `want` once L(p,p) and Dinv(p), and then L(p+1,p), are in memory --
+// what the update stream's full-height solve and look-ahead update of the same step poll (GemmNT::wait_flag) instead of
+// waiting for this kernel to end.
+int launch_potf2_chain(double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, const unsigned* flag, unsigned want,
+                       hipStream_t s, unsigned* done_leaf = nullptr, unsigned* done_t1 = nullptr, int do_t2 = 1);
+int launch_flag_set(unsigned* flag, unsigned v, hipStream_t s);
+int launch_flag_probe(const unsigned* flag, unsigned want, unsigned* seen, hipStream_t s);  // gpk_init: are cross-stream flags usable here?
 
 // ---------------------------------------------------------------- builders
 struct SEParams {

@@ -105,6 +105,7 @@ extern "C" int gpk_pref_laplace(gpk_model* m, const long long* uvi, const double
     PREF_HIP(hipMemcpyAsync(&ferr, dscal, 8, hipMemcpyDeviceToHost, s));
     PREF_HIP(hipMemcpyAsync(&binfo, mb->dinfo, 4, hipMemcpyDeviceToHost, s));
     PREF_HIP(hipStreamSynchronize(s));
+    if (!rc) rc = info_timeout_rc(binfo);
     if (!rc && binfo > 0) rc = gpk_set_err(-4, "Newton system lost positive definiteness (minor %d)", binfo);
     if (rc) break;
     std::swap(df, dfn);
@@ -212,6 +213,7 @@ extern "C" int gpk_pref_predict(gpk_model* m, const long long* uvi, const double
   PREF_HIP(hipMemcpyAsync(mean_out, dmean, (size_t)M * 8, hipMemcpyDeviceToHost, s));
   PREF_HIP(hipMemcpyAsync(var_out, dvar, (size_t)M * 8, hipMemcpyDeviceToHost, s));
   PREF_HIP(hipStreamSynchronize(s));
+  if (!rc) rc = info_timeout_rc(binfo);
   if (!rc && binfo > 0) rc = gpk_set_err(-4, "gpk_pref_predict: B lost positive definiteness (minor %d)", binfo);
 #undef PREF_HIP
 #undef PREF_DO

@@ -56,6 +56,21 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
+  if (g.wait_flag) {
+    // resident before the producer has finished (tile pipeline: the chain kernel raises the flag in mid-flight): poll, bounded
+    if (tid == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while ((int)(__hip_atomic_load(g.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.wait_val) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) {  // 4 ms
+          if (g.wait_info) atomicCAS(g.wait_info, 0, 1 << 30);     // GPK_INFO_TIMEOUT
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
 
   // ---- tile decode
   int ti, tj;
@@ -595,6 +610,7 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
     return gpk_set_err(-1, "gemm_nt: operands must be 16-byte aligned with even leading dimensions");
   if (g.lda >= (1l << 22) || g.ldb >= (1l << 22))  // LDS-DMA staging: 128 rows of an operand within a 32-bit byte offset
     return gpk_set_err(-1, "gemm_nt: leading dimensions must stay below 2^22");
+  if (g.wait_flag && tile128) return gpk_set_err(-1, "gemm_nt: only the 64x64-tile kernel polls a flag");
   if (g.k1 > 0) {  // two separately stored operands: a table of two segments
     if (!tile128 || g.cyc_P != 0) return gpk_set_err(-1, "gemm_nt: a second K segment needs the 8-wave single-GPU kernel");
     if (g.k1 >= g.k || !g.A2 || !g.B2) return gpk_set_err(-1, "gemm_nt: bad second K segment (k1=%d k=%d)", g.k1, g.k);

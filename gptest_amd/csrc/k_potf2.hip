@@ -510,6 +510,157 @@ __global__ __launch_bounds__(1024) void potf2_trtri_128_kernel(const double* __r
   leaf_body(A, lda, L, ldl, Dinv, info, col0, dbg_skip, S, rinvb, failflag, (int)threadIdx.x);
 }
 
+// ---------------------------------------------------------------- one launch per chain step (tile pipeline, potrf_tail)
+// Step p of the tile pipeline used to be three dependent launches on the chain stream: the leaf of tile (p,p), then
+// T1: L(p+1,p) = A(p+1,p) Dinv(p)^T and T2: A(p+1,p+1) -= L(p+1,p) L(p+1,p)^T as one-tile GEMMs (7 us each plus a launch gap
+// each).  Here the full-tile leaf goes on, on its own CU, with both products: Dinv is already in LDS (B operand of T1), the
+// rows of A(p+1,p) come straight from L2 (32 values per lane, one load latency), L(p+1,p) is written to the packed panel and
+// into LDS (row stride CLD: conflict-free fragment reads) for T2.  Every output element is ONE MFMA chain over k in ascending
+// order, started from zero (T1) or from the stored value (T2), exactly as in gemm_tile128_kernel -- the k-blocks of T1 beyond
+// the diagonal of Dinv are exact zeros there and skipped here -- so the factor is bit for bit that of the three launches
+// (tests).  The two tiles of row p+1 carry the look-ahead update of step p-1, which runs on the UPDATE stream while this
+// kernel factors tile (p,p): instead of an event in front of the launch the kernel polls a flag that the update stream sets
+// behind that update (launch_flag_set), after the leaf and before it touches row p+1.  Bounded: after GPK_CHAIN_WAIT_TICKS of
+// the 100 MHz clock the kernel gives up and poisons *info (GPK_INFO_TIMEOUT -> an error on the host, never a hang).
+#define CLD 146
+constexpr unsigned long long GPK_CHAIN_WAIT_TICKS = 400000ull;  // 4 ms
+
+template <int J0, int J1, int J2, int J3>
+static __device__ __forceinline__ void chain_t1(const double (&a)[32], const double* S, int fr, int fg, d4 (&acc)[4]) {
+  constexpr int Js[4] = {J0, J1, J2, J3};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double* Bp = S + (16 * Js[u] + fr) * PLD + fg;  // rows of Dinv = columns of the product; Dinv[c][k] = 0 for k > c
+#pragma unroll
+    for (int q = 0; q < 4 * (Js[u] + 1); ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], Bp[4 * q], acc[u], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(1024) void potf2_chain_kernel(double* __restrict__ A, long lda, double* __restrict__ L, long ldl,
+                                                           double* __restrict__ Dinv, int* info, int col0, const unsigned* flag,
+                                                           unsigned want, unsigned* done_leaf, unsigned* done_t1, int do_t2) {
+  __shared__ __attribute__((aligned(16))) double S[128 * CLD];  // the leaf's 128 x PLD image first, the image of L(p+1,p) later
+  __shared__ double rinvb[16];
+  __shared__ int failflag;
+  const int tid = (int)threadIdx.x;
+  leaf_body(A, lda, L, ldl, Dinv, info, col0, 0, S, rinvb, failflag, tid);
+  __syncthreads();
+  if (failflag) {  // identity factors went out for this tile (leaf_body): the two products go on with them
+    for (int e = tid; e < 128 * 128; e += 1024) S[(e >> 7) * PLD + (e & 127)] = ((e >> 7) == (e & 127)) ? 1.0 : 0.0;
+    __syncthreads();
+  }
+  const int lane = tid & 63, wv = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  if (done_leaf) {
+    // L(p,p) and Dinv(p) are out: the full-height solve of this step, already resident on the update stream and polling this
+    // flag (GemmNT::wait_flag), can go on while this kernel does the two tile products
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(done_leaf, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (flag) {
+    if (tid == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > GPK_CHAIN_WAIT_TICKS) {
+          atomicCAS(info, 0, 1 << 30);  // GPK_INFO_TIMEOUT (gpk_core.h)
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // row p+1 was written by another kernel while this one was running
+  }
+  // ---- T1: L(p+1,p) = A(p+1,p) Dinv^T.  Wave (I, half): block row I, block columns {0,3,4,7} or {1,2,5,6} (18 k-blocks each).
+  const int I = wv & 7, half = wv >> 3;
+  const double* A1 = A + 128 * lda;
+  double* C2 = A + 128 * lda + 128;
+  double a[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) a[q] = A1[(long)(16 * I + fr) * lda + 4 * q + fg];
+  d4 acc[4];
+  if (half == 0) chain_t1<0, 3, 4, 7>(a, S, fr, fg, acc);
+  else chain_t1<1, 2, 5, 6>(a, S, fr, fg, acc);
+  // the accumulators of T2 start as the stored tile: requested now (the operand registers of T1 are free), needed two barriers on
+  d4 c2[3];
+  int ti2[3], tj2[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int t = wv + 16 * u;  // lower 16x16 blocks in triangular numbering, 36 of them over 16 waves
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    ti2[u] = bi;
+    tj2[u] = t - bi * (bi + 1) / 2;
+    if (t < 36 && do_t2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c2[u][r] = C2[(long)(16 * ti2[u] + fg + 4 * r) * lda + 16 * tj2[u] + fr];
+    }
+  }
+  __syncthreads();  // every wave has its fragments of Dinv: the image can go
+  double* L1 = L + 128 * ldl;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int J = half == 0 ? (u == 0 ? 0 : u == 1 ? 3 : u == 2 ? 4 : 7) : (u == 0 ? 1 : u == 1 ? 2 : u == 2 ? 5 : 6);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + fg + 4 * r, col = 16 * J + fr;
+      L1[(long)row * ldl + col] = acc[u][r];
+      S[row * CLD + col] = acc[u][r];
+    }
+  }
+  if (done_t1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // L(p+1,p) is out: the look-ahead update of this step may read it
+  __syncthreads();
+  if (done_t1 && tid == 0) __hip_atomic_store(done_t1, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- T2: A(p+1,p+1) -= L(p+1,p) L(p+1,p)^T, lower blocks (not at the end of a batch of the batched pipeline: tile (p+1,p+1) then
+  //      belongs to the bulk stream's look-ahead update of the next batch)
+  if (!do_t2) return;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    if (wv + 16 * u < 36) {
+      const double* Ap = S + (16 * ti2[u] + fr) * CLD + fg;
+      const double* Bp = S + (16 * tj2[u] + fr) * CLD + fg;
+      d4 c = c2[u];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[4 * q], Bp[4 * q], c, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) C2[(long)(16 * ti2[u] + fg + 4 * r) * lda + 16 * tj2[u] + fr] = c[r];
+    }
+  }
+}
+
+__global__ void flag_set_kernel(unsigned* flag, unsigned v) {
+  __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+int launch_flag_set(unsigned* flag, unsigned v, hipStream_t s) {
+  hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, s, flag, v);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+// probe (gpk_init): can a kernel on one stream see a flag that a LATER launch on another stream sets while it runs?  Under a tool
+// that serialises dispatches (rocprofv3 --pmc) it cannot, and the fused chain step must not be used there.
+__global__ void flag_probe_kernel(const unsigned* flag, unsigned want, unsigned* seen) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned ok = 0;
+  do {
+    if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) { ok = 1; break; }
+    __builtin_amdgcn_s_sleep(8);
+  } while (__builtin_amdgcn_s_memrealtime() - t0 < 50000ull);  // 0.5 ms
+  *seen = ok;
+}
+int launch_flag_probe(const unsigned* flag, unsigned want, unsigned* seen, hipStream_t s) {
+  hipLaunchKernelGGL(flag_probe_kernel, dim3(1), dim3(1), 0, s, flag, want, seen);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_potf2_chain(double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, const unsigned* flag, unsigned want,
+                       hipStream_t s, unsigned* done_leaf, unsigned* done_t1, int do_t2) {
+  hipLaunchKernelGGL(potf2_chain_kernel, dim3(1), dim3(1024), 0, s, A, lda, L, ldl, Dinv, info, col0, flag, want, done_leaf, done_t1, do_t2);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
 // fat: the full-tile form (the caller expects an empty CU to be easy to find), else the slot-sized one
 int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0,
                            int dbg_skip, hipStream_t s, int fat) {

@@ -45,6 +45,10 @@ int gpk_bench_chain_step(int reps, int nsmall, int small_m, double* us_alone, do
 int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_out);
 /* device-resident timing of the MFMA GEMM: C (m x n) -= A (m x k) B (n x k)^T, `reps` launches; ms per launch. */
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out);
+/* probe: nstreams streams (bit i of high_mask / low_mask: highest / lowest priority, else normal; use_lib_streams: the first three are the
+ * library's own update / chain / substitution streams), `reps` small spinning launches (wgs workgroups, us_each microseconds) on each,
+ * queued round robin.  out_us[i] = time per launch on stream i, out_us[nstreams] = host wall time per round. */
+int gpk_bench_streams(int nstreams, int high_mask, int low_mask, int wgs, int us_each, int reps, int use_lib_streams, double* out_us);
 /* LDS banking probe for rocprofv3 --pmc (scripts/lds_bank_probe.sh): `reps` ds_read_b64 per lane in one of six address patterns. */
 int gpk_bench_lds_bank_probe(int pattern, int reps);
 /* leaf kernel timing; dbg_skip bit 0 = skip elimination, bit 1 = skip inverse (timing only), bit 8 = the full-tile form. */
@@ -52,6 +56,10 @@ int gpk_bench_leaf(int dbg_skip, int reps, double* us_out);
 /* leaf on the chain stream, alone and while the update stream saturates the chip (reps bit 24: the full-tile form,
  * bits 16..23: dbg_skip). */
 int gpk_bench_leaf_contended(int reps, double* us_alone, double* us_contended);
+/* one chain step of the tile pipeline on a 256 x 256 block B (lower tiles): leaf of tile (0,0), L(1,0) = B(1,0) inv(L(0,0))^T, B(1,1) -= L(1,0) L(1,0)^T.
+ * mode 0: three launches; 1: the fused kernel; 2: the fused kernel polling a flag that the update stream sets meanwhile; 3: a flag nobody sets
+ * (returns -3 once the bounded wait gives up).  L_out 256 x 128, Dinv_out 128 x 128, A11_out 128 x 128.  Returns info. */
+int gpk_test_chain_step(const double* B, double* L_out, double* Dinv_out, double* A11_out, int mode);
 /* factor one 128x128 SPD tile: L_out (128x128 lower) and Dinv_out = inv(L); full_tile: the 1024-thread form instead of
  * the slot-sized one (bit-identical results).  Returns info. */
 int gpk_test_potf2_128(const double* A, double* L_out, double* Dinv_out, int full_tile);

@@ -23,12 +23,14 @@ def _bind(l):
         "gpk_test_gemm_nt": (i, [dp, dp, dp, i, i, i, i, i, i, i, i]),
         "gpk_test_gemm_segs": (i, [dp, dp, dp, i, i, ip, ip, i, i]),
         "gpk_test_potf2_128": (i, [dp, dp, dp, i]),
+        "gpk_test_chain_step": (i, [dp, dp, dp, dp, i]),
         "gpk_test_dist_potrf": (i, [dp, i, i, dp]),
         "gpk_test_dist_fit": (i, [dp, i, i, dp, d, i, dp]),
         "gpk_test_dist_posterior": (i, [dp, dp, i, i, dp, dp, i, i, dp, dp, dp]),
         "gpk_bench_se_build": (i, [i, i, i, i, i, dp]),
         "gpk_bench_gemm_nt": (i, [i, i, i, i, i, i, dp]),
         "gpk_bench_lds_bank_probe": (i, [i, i]),
+        "gpk_bench_streams": (i, [i, i, i, i, i, i, i, dp]),
         "gpk_bench_leaf": (i, [i, i, dp]),
         "gpk_bench_leaf_contended": (i, [i, dp, dp]),
         "gpk_bench_chain_step": (i, [i, i, i, dp, dp]),

@@ -18,6 +18,7 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t) {
   if (g.m % BT || g.n % BT || g.k % 16 || g.k <= 0) return gpk_set_err(-1, "gemm_nt: bad shape m=%d n=%d k=%d (tile %d)", g.m, g.n, g.k, BT);
   if ((g.lda & 1) || (g.ldb & 1)) return gpk_set_err(-1, "gemm_nt: odd leading dimension");
   if (g.lower && g.cyc_P == 0 && g.m < g.n) return gpk_set_err(-1, "gemm_nt: lower needs m >= n");
+  if (g.wait_flag && (tile128 || (int)(*g.wait_flag - g.wait_val) < 0)) return gpk_set_err(-1, "hostsim: a polling launch was queued before its producer");
   if (g.k1 > 0 && (g.k1 % 16 || g.k1 >= g.k || !g.A2 || !g.B2 || (g.lda2 & 1) || (g.ldb2 & 1) || g.cyc_P != 0 || !tile128))
     return gpk_set_err(-1, "gemm_nt: bad second K segment");
   const int ntm = g.m / BT, ntn = g.n / BT;
@@ -136,6 +137,24 @@ int launch_potf2_trtri_128(const double* A, long lda, double* L, long ldl, doubl
     }
   return 0;
 }
+
+// the fused chain step: the leaf, then the two one-tile products exactly as the separate launches do them
+int launch_potf2_chain(double* A, long lda, double* L, long ldl, double* Dinv, int* info, int col0, const unsigned* flag, unsigned want, hipStream_t s,
+                       unsigned* done_leaf, unsigned* done_t1, int do_t2) {
+  if (done_leaf) *done_leaf = want;
+  if (done_t1) *done_t1 = want;
+  if (flag && (int)(*flag - want) < 0) return gpk_set_err(-1, "hostsim: the fused chain step was queued before the look-ahead update it waits for");
+  GPK_TRY(launch_potf2_trtri_128(A, lda, L, ldl, Dinv, info, col0, 0, s, 1));
+  GemmNT t1{};
+  t1.A = A + 128 * lda; t1.lda = lda; t1.B = Dinv; t1.ldb = 128; t1.C = L + 128 * ldl; t1.ldc = ldl; t1.m = t1.n = t1.k = 128;
+  GPK_TRY(launch_gemm_tile128(t1, s));
+  if (!do_t2) return 0;
+  GemmNT t2{};
+  t2.A = L + 128 * ldl; t2.lda = ldl; t2.B = t2.A; t2.ldb = ldl; t2.C = A + 128 * lda + 128; t2.ldc = lda; t2.m = t2.n = t2.k = 128; t2.sub = 1; t2.lower = 1;
+  return launch_gemm_tile128(t2, s);
+}
+int launch_flag_set(unsigned* flag, unsigned v, hipStream_t) { *flag = v; return 0; }
+int launch_flag_probe(const unsigned* flag, unsigned want, unsigned* seen, hipStream_t) { (void)flag; (void)want; *seen = 1; return 0; }  // (the host simulation runs every stream in enqueue order)
 
 int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p, int same_set,
                     int mode, double* out, long ld, long lower_only, hipStream_t, int col_g0, const double*, const SEParams*) {

@@ -15,3 +15,4 @@ HOSTSIM_ABSENT(gpk_bench_lds_bank_probe(int, int))
 HOSTSIM_ABSENT(gpk_bench_leaf(int, int, double*))
 HOSTSIM_ABSENT(gpk_bench_leaf_contended(int, double*, double*))
 HOSTSIM_ABSENT(gpk_bench_mfma_pinned(int, int, double*))
+HOSTSIM_ABSENT(gpk_bench_streams(int, int, int, int, int, int, int, double*))

@@ -263,6 +263,42 @@ def test_slot_sized_leaf_is_bitwise_the_full_tile_leaf(gpk):
             assert np.array_equal(L, np.eye(128)) and np.array_equal(D, np.eye(128))  # identity factors keep downstream kernels finite
 
 
+def test_fused_chain_step_is_bitwise_leaf_and_two_tile_products(gpk):
+    """potf2_chain_kernel: the leaf of tile (p,p), L(p+1,p) = A(p+1,p) Dinv^T and A(p+1,p+1) -= L(p+1,p) L(p+1,p)^T in ONE launch on
+    one CU, polling a flag for row p+1 instead of waiting for an event.  Bit for bit the three launches it replaces -- with the
+    flag absent, set from the other stream while the kernel runs, and with a non-positive pivot (identity factors go on into both
+    products); a flag that never comes is an error after the bounded wait, not a hang."""
+    rng = np.random.RandomState(5)
+    Q = rng.randn(256, 300)
+    B = Q @ Q.T / 300 + 0.5 * np.eye(256)
+
+    def step(Bm, mode):
+        L, D, A11 = np.zeros((256, 128)), np.zeros((128, 128)), np.zeros((128, 128))
+        rc = hooks().gpk_test_chain_step(_ptr(np.ascontiguousarray(Bm)), _ptr(L), _ptr(D), _ptr(A11), mode)
+        return rc, L, D, A11
+
+    rc0, L0, D0, A0 = step(B, 0)
+    assert rc0 == 0, gpk.last_error()
+    for mode in (1, 2):
+        rc, L, D, A11 = step(B, mode)
+        assert rc == 0, gpk.last_error()
+        np.testing.assert_array_equal(L, L0)
+        np.testing.assert_array_equal(D, D0)
+        np.testing.assert_array_equal(np.tril(A11), np.tril(A0))
+    Lr = np.linalg.cholesky(B)
+    np.testing.assert_allclose(L0, Lr[:, :128], rtol=1e-11, atol=1e-12)
+    S = B[128:, 128:] - Lr[128:, :128] @ Lr[128:, :128].T
+    np.testing.assert_allclose(np.tril(A0), np.tril(S), rtol=1e-10, atol=1e-12)
+    Bb = B.copy()
+    Bb[40, 40] = -1.0
+    r0 = step(Bb, 0)
+    r1 = step(Bb, 1)
+    assert r0[0] == 41 and r1[0] == 41
+    for x, y in zip(r0[1:], r1[1:]):
+        np.testing.assert_array_equal(np.tril(x) if x.shape == (128, 128) else x, np.tril(y) if y.shape == (128, 128) else y)
+    assert step(B, 3)[0] == -3 and "timed out" in gpk.last_error()
+
+
 @pytest.mark.parametrize("N", [1, 2, 5, 127, 128, 129, 300, 640, 1111, 2048])
 def test_potrf_matches_numpy(gpk, N):
     rng = np.random.RandomState(N)
@@ -337,19 +373,24 @@ def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_fro
     Q = rng.randn(N, N)
     A = Q @ Q.T + N * np.eye(N)
     out = []
-    for tail in (0, 1):
+    assert gpk.get_option("flags_ok") == 1  # (the plain runtime lets a running kernel see another stream's later flag)
+    for tail in (0, 1, 2, 3):  # 1: leaf + two one-tile kernels per step, 2: one launch per step (potf2_chain_kernel), 3: ... whose flags the update stream polls
         for k, v in opts.items():
             gpk.set_option(k, 0 if (k == "tail_rows" and not tail) else v)
         gpk.set_option("pair_update", 0)
+        gpk.set_option("chain_fused", max(tail - 1, 0))
         L = A.copy()
         assert gpk.lib().gpk_potrf(_ptr(L), N) == 0, gpk.last_error()
         tf = gpk.get_option("potrf_tail_from")
         if tail:
             assert tf >= 0 and (tail_from is None or tf == tail_from)
+            assert (gpk.get_option("potrf_chain_fused") > 0) == (tail >= 2)
         else:
             assert tf == -1
         out.append(L)
     np.testing.assert_array_equal(out[0], out[1])
+    np.testing.assert_array_equal(out[0], out[2])
+    np.testing.assert_array_equal(out[0], out[3])
     Lr = np.linalg.cholesky(A)
     np.testing.assert_allclose(out[1], Lr, rtol=1e-11, atol=1e-11 * np.abs(Lr).max())
     # not positive definite inside the tail: same LAPACK-style report
@@ -1641,10 +1682,12 @@ def test_shutdown_reinit_and_clean_process_exit(gpk):
     from conftest import ROOT
 
     code = """
-import ctypes, sys
+import ctypes, os, sys
 sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(sys.path[0], "tests"))
 import numpy as np
 from gptest_amd import _lib, GPr
+from gpk_hooks import hooks
 _lib.init()
 l = _lib.lib()
 ms = ctypes.c_double()
