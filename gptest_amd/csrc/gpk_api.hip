@@ -104,7 +104,6 @@ void gpk_shutdown(void) {
   g_cu_guest = nullptr;
   if (G.dctr) (void)hipFree(G.dctr);
   G.dctr = nullptr;
-  graph_cache_clear();
   for (auto& kv : G.hpin_pool)
     for (double* q : kv.second) (void)hipHostFree(q);
   G.hpin_pool.clear();
@@ -133,8 +132,6 @@ int gpk_sync(void) {
 int gpk_set_option(const char* key, double value) {
   std::string k(key ? key : "");
   const int v = (int)value;
-  G.opt_epoch++;          // a launch graph captured under other options is never replayed
-  graph_cache_clear();
   if (k == "nb") {  // 0: the automatic 512 / 256 / 128 schedule (default); otherwise uniform panels of this width
     if (v < 0 || v % 128) return gpk_set_err(-1, "option nb=%d must be 0 (automatic) or a positive multiple of 128", v);
     G.nb = v;
@@ -151,6 +148,8 @@ int gpk_set_option(const char* key, double value) {
   } else if (k == "dist_group") {
     if (v < 1 || v > 64) return gpk_set_err(-1, "dist_group must be in 1..64");
     G.dist_group = v;
+  } else if (k == "dist_pipeline") {
+    G.dist_pipeline = v ? 1 : 0;
   } else if (k == "tail_rows") {
     G.tail_rows = v;
   } else if (k == "leaf_fat_rows") {  // the full-tile leaf once at most this many rows remain; -1: never, 1 << 30: always
@@ -192,8 +191,6 @@ int gpk_set_option(const char* key, double value) {
   } else if (k == "corner_prio") {
     if (v < 0 || v > 2) return gpk_set_err(-1, "option corner_prio=%d must be 0, 1 or 2", v);
     G.corner_prio = v;
-  } else if (k == "graphs") {
-    G.graphs = v ? 1 : 0;
   } else if (k == "stamps") {
     G.stamps = v;
   } else if (k == "timing") {
@@ -213,6 +210,7 @@ double gpk_get_option(const char* key) {
   if (k == "outer_until") return G.outer_until;
   if (k == "lookahead") return G.lookahead;
   if (k == "dist_group") return G.dist_group;
+  if (k == "dist_pipeline") return G.dist_pipeline;
   if (k == "tail_rows") return G.tail_rows;
   if (k == "leaf_fat_rows") return G.leaf_fat_rows;
   if (k == "gemm_polite") { extern int g_gemm_polite; return g_gemm_polite; }
@@ -235,12 +233,8 @@ double gpk_get_option(const char* key) {
   if (k == "potrf_corner_from") return g_potrf_corner[0];
   if (k == "potrf_corner_from2") return g_potrf_corner[1];
   if (k == "potrf_corner_from3") return g_potrf_corner[2];
-  if (k == "graphs") return G.graphs;
   if (k == "stamps") return G.stamps;
   if (k == "timing") return G.timing;
-  if (k == "graph_captures") return (double)G.graph_captures;
-  if (k == "graph_replays") return (double)G.graph_replays;
-  if (k == "graph_fallback") return G.graph_fallback.empty() ? 0.0 : 1.0;
   // read-only state
   if (k == "pool_bytes") return (double)G.pool_bytes;
   if (k == "potrf_enqueue_ms") return G.last_potrf_enqueue_ms;

@@ -60,6 +60,14 @@ int gpk_comm_init(int rank, int nranks, const void* uid128) {
   // A multi-rank process gets a COMMUNICATION stream on top of the three of the one-GPU layout: the panel broadcasts run there, off
   // the panel chain (potrf_group).  The substitution stream stays (round 4): y and this rank's shard of the prediction are
   // substituted on it behind the per-panel "available" events (fit_group_impl), as on one GPU.
+  // (option dist_pipeline = 0: the round-3 layout -- three streams, the substitution stream given up for the communication stream,
+  //  prediction after the factorisation.  A fourth stream is not free on this runtime: two hardware queues can end up time-sliced on one
+  //  pipe, profiles/r04_stream_probe.txt; which layout wins on a real node has to be measured there.)
+  if (!G.dist_pipeline && G.s_pred && G.s_pred != G.s_panel) {
+    (void)hipStreamSynchronize(G.s_pred);
+    (void)hipStreamDestroy(G.s_pred);
+    G.s_pred = nullptr;
+  }
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
   if (hipStreamCreateWithPriority(&G.s_comm, hipStreamNonBlocking, hi) != hipSuccess) {

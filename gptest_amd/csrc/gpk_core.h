@@ -41,6 +41,8 @@ struct Runtime {
   int nb_outer = 2048, outer_until = 8192;
   int lookahead = 1;
   int dist_group = 2;   // panels (of the middle width) per ownership block of a block-cyclic (multi-GPU) model
+  int dist_pipeline = 1;  // multi-rank process: keep the substitution stream next to the communication stream and pipeline y / this rank's
+                          // shard of the prediction behind the per-panel "available" events (fit_group_impl); 0: three streams, prediction afterwards
   // tile pipeline (potrf_tail) for the chain-bound last tail_rows columns (needs 128-wide panels there: nb_small_from);
   // 0 = the panel-level look-ahead everywhere
   int tail_rows = 4096;
@@ -66,25 +68,14 @@ struct Runtime {
   int corner_hold = 0;  // no catch-up launch starts before the panel that begins at or after this column has been factored: the deferred work
                         // is held back until the factorisation turns chain-bound instead of competing with the bulk-bound first part
   // tile pipeline: leaf + the two one-tile GEMMs of a step as ONE launch (potf2_chain_kernel) that polls a flag for the update
-  // stream's look-ahead update instead of waiting for an event in front of the launch.  -1: automatic (on where cross-stream flags
-  // work: flags_ok, probed by gpk_init -- they do not under a tool that serialises dispatches -- and never inside a graph capture)
-  int chain_fused = -1;
+  // stream's look-ahead update instead of waiting for an event in front of the launch.  0: off (default: measured slower, DESIGN.md
+  // section 6), 1: on, 2: on, and the update stream's kernels poll the flags the chain kernel raises; -1: 2 where cross-stream flags
+  // work (flags_ok, probed by gpk_init: they do not under a tool that serialises dispatches)
+  int chain_fused = 0;
   int flags_ok = 0;
-  bool capturing = false;
   unsigned flag_epoch = 0;     // one value per tile-pipeline run: a stale flag of an earlier run never satisfies a wait
   int small_tile_below = 256;  // panel_update: launches with fewer 128x128 tiles than this use the 64x64-tile kernel
-  // launch graphs (fit_device, option graphs): the whole multi-stream enqueue of one fit (+ fused prediction) captured once
-  // per (shape, buffers, schedule) and replayed afterwards -- the reference's caller evaluates one shape hundreds of times
-  // (GP_regression_demo.py:44) and below N ~ 8192 the host needs as long to queue the ~700 launches as the device to run
-  // them.  Bit-identical to the eager run (tests) and OFF by default: on ROCm 7.2 the replay of this three-stream DAG takes
-  // twice as long as the eager enqueue (N = 4096: 6.3 against 3.1 ms, N = 16384: 43.4 against 33.6).
-  int graphs = 0;
-  unsigned long long opt_epoch = 0;  // bumped by every gpk_set_option: cached graphs of another schedule are never replayed
-  struct GraphEntry { std::vector<unsigned long long> key; void* exec; unsigned long long last_use; };
-  std::vector<GraphEntry> graph_cache;
   std::map<size_t, std::vector<double*>> hpin_pool;  // pinned read-back buffers of destroyed models, by size in doubles
-  unsigned long long graph_clock = 0, graph_captures = 0, graph_replays = 0;
-  std::string graph_fallback;  // why the last fit that wanted a graph ran eagerly ("" = it did not)
   int timing = 0;
   int stamps = 0;  // diagnostic: device-side progress stamps per panel (gpk_get_option("stamp_panel_<p>" / "stamp_subst_<p>"), scripts/stamp_steps.py)
   unsigned long long* dstamps = nullptr;
@@ -180,7 +171,6 @@ struct gpk_model {
   double *dX = nullptr, *dy = nullptr, *dw = nullptr;
   double *dK = nullptr, *dKcopy = nullptr, *dL = nullptr, *dDinv = nullptr;
   double* dscal = nullptr;  // [0] sum log diag L  [1] w.w
-  SEParams* dse = nullptr;  // the hyper-parameters in device memory: what a replayed launch graph reads (fit_device)
   double* hpin = nullptr;   // pinned host staging of a fit's read-back: [sum log diag L, w.w, info, -, mean(M), var(M)]
   size_t hpin_doubles = 0;
   double* dws = nullptr;    // gemvT workspace 64*NB
@@ -216,7 +206,6 @@ struct FusedPredict {
   double *h_mean = nullptr, *h_var = nullptr;  // host destinations: read back together with the scalars (one sync)
 };
 int fit_device(gpk_model* m, const FusedPredict* fp = nullptr);  // K build + potrf + w + scalars (inputs resident)
-void graph_cache_clear();
 extern int g_potrf_lookahead_used;  // 1 if the last potrf_device recorded per-panel events in m->ev[0..nP)
 extern int g_dist_lookahead_used;   // 1 if the last block-cyclic factorisation ran the look-ahead schedule
 int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel = nullptr);                                 // dK -> dL, dDinv

@@ -213,7 +213,6 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   rc |= dev_alloc_t(&m->dL, m->L_elems);
   rc |= dev_alloc_t(&m->dDinv, (size_t)m->nT * 128 * 128);
   rc |= dev_alloc_t(&m->dscal, 8);
-  rc |= dev_alloc(reinterpret_cast<void**>(&m->dse), sizeof(SEParams));
   m->dws_bytes = (size_t)64 * std::max(nb, G.nb_big) * 8;
   rc |= dev_alloc(reinterpret_cast<void**>(&m->dws), m->dws_bytes);
   rc |= dev_alloc_t(&m->dinfo, 4);
@@ -229,14 +228,13 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
 
 // Buffers and events go back in the REVERSE order of model_create / model_events, so that the next model of the same shape
 // -- an optimiser evaluates one shape hundreds of times, GP_regression_demo.py:44 -- gets the very same pointers and event
-// handles back from the pools field by field: its launch graph is then found in the cache (fit_device) instead of captured.
+// handles back from the pools field by field.
 void model_destroy(gpk_model* m) {
   if (!m) return;
   const size_t np = m->Npad;
   dev_free(m->dflags, (size_t)3 * m->nT * sizeof(unsigned));
   dev_free(m->dinfo, 16);
   dev_free(m->dws, m->dws_bytes);
-  dev_free(m->dse, sizeof(SEParams));
   dev_free(m->dscal, 64);
   dev_free(m->dDinv, (size_t)m->nT * 128 * 128 * 8);
   dev_free(m->dL, m->L_elems * 8);
@@ -519,7 +517,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
   hipEvent_t* ev_near = m->ev.data() + 5 * nP + 6;
   if (ev_prev_rest) GPK_HIP(hipStreamWaitEvent(sm, ev_prev_rest, 0));
   // one launch per chain step (potf2_chain_kernel) where the full-tile leaf is used and cross-stream flags work
-  const bool fused_ok = (G.chain_fused > 0 || (G.chain_fused < 0 && G.flags_ok)) && !G.capturing && m->dflags;
+  const bool fused_ok = (G.chain_fused > 0 || (G.chain_fused < 0 && G.flags_ok)) && m->dflags;
   const unsigned epoch = ++G.flag_epoch;
   g_potrf_chain_fused = 0;
   for (int p = p_first; p < nP; ++p) {
@@ -1173,7 +1171,7 @@ static int fit_group_impl(gpk_model* const* ms, int n, const GroupPredict* gp) {
   GPK_TRY(potrf_group(ms, n));
   timer_end("potrf", s);
   hipStream_t sq = G.s_pred;
-  const bool pipelined = sq && G.fuse_predict && g_dist_lookahead_used;  // (virtual ranks: the stand-in broadcasts share this stream -- queued first, so the substitutions follow them)
+  const bool pipelined = sq && G.fuse_predict && G.dist_pipeline && g_dist_lookahead_used;  // (virtual ranks: the stand-in broadcasts share this stream -- queued first, so the substitutions follow them)
   g_dist_pipelined = pipelined ? 1 : 0;
   for (int i = 0; i < n; ++i) {
     gpk_model* m = ms[i];
@@ -1250,18 +1248,16 @@ static int fit_group_impl(gpk_model* const* ms, int n, const GroupPredict* gp) {
 int fit_group(gpk_model* const* ms, int n) { return fit_group_impl(ms, n, nullptr); }
 
 // Everything one fit queues on the three streams, from the K build to the read-back into the model's pinned staging
-// buffer -- no synchronisation, no allocation of device memory: the body fit_device either runs eagerly or captures into
-// a launch graph.  dse: hyper-parameters from device memory (graph mode) or nullptr (by value).
-static int fit_enqueue(gpk_model* m, const FusedPredict* fp, const SEParams* dse) {
+// buffer -- no synchronisation, no allocation of device memory.
+static int fit_enqueue(gpk_model* m, const FusedPredict* fp) {
   hipStream_t s = G.s_main;
   const int np_ = m->Npad;
-  const double* sf2_dev = dse ? &dse->sf2 : nullptr;
   if (G.stamps && G.dstamps) {
     GPK_HIP(hipMemsetAsync(G.dstamps, 0, 1024 * 8, s));
     GPK_TRY(launch_stamp(G.dstamps + 447, s));  // "stamp_start": the fit begins (before the K build)
   }
   timer_begin("kbuild", s, (m->keep_k ? 8.0 : 4.0) * np_ * np_ + 8.0 * m->N * m->d);
-  GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s, 0, nullptr, dse));
+  GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s));
   timer_end("kbuild", s);
   if (m->keep_k)
     GPK_HIP(hipMemcpy2DAsync(m->dKcopy, (size_t)np_ * 8, m->dK, (size_t)m->ldk * 8, (size_t)np_ * 8, np_, hipMemcpyDeviceToDevice, s));
@@ -1308,7 +1304,7 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp, const SEParams* dse
     if (m->has_y) GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, sy));
     if (fuse) {
       timer_begin("predict", sq);
-      GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq, 0, nullptr, dse));
+      GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq));
     }
   }
   const auto host_t0 = std::chrono::steady_clock::now();
@@ -1346,7 +1342,7 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp, const SEParams* dse
   }
   if (fp) {
     if (fused_done) {
-      GPK_TRY(launch_row_stats(fp->dV, np_, fp->M, np_, m->dw, m->se.sf2, fp->dmean, fp->dvar, s, sf2_dev));
+      GPK_TRY(launch_row_stats(fp->dV, np_, fp->M, np_, m->dw, m->se.sf2, fp->dmean, fp->dvar, s));
     } else {
       GPK_TRY(predict_device(m, fp->dZ, fp->M, fp->Mpad, fp->dR, fp->dV, fp->dmean, fp->dvar));
     }
@@ -1362,14 +1358,6 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp, const SEParams* dse
   return 0;
 }
 
-void graph_cache_clear() {
-#ifndef GPK_HOSTSIM
-  for (auto& e : G.graph_cache)
-    if (e.exec) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
-#endif
-  G.graph_cache.clear();
-}
-
 int fit_device(gpk_model* m, const FusedPredict* fp) {
   hipStream_t s = G.s_main;
   if (m->P > 1) {
@@ -1379,7 +1367,7 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     return fit_group(&one, 1);
   }
   if (m->k_only && !m->keep_k) return gpk_set_err(-1, "internal: a K-only model must keep K");
-  // everything the enqueue may allocate is allocated up front (a captured enqueue must not touch the allocator)
+  // the pinned read-back buffer (pooled by size: a destroyed model's buffer serves the next model of that shape)
   const size_t need = 4 + (fp ? 2 * (size_t)fp->M : 0);
   if (m->hpin_doubles < need) {
     if (m->hpin) G.hpin_pool[m->hpin_doubles].push_back(m->hpin);
@@ -1398,88 +1386,9 @@ int fit_device(gpk_model* m, const FusedPredict* fp) {
     G.hstamps.assign(1024, 0);
   }
   GPK_TRY(model_events(m, 10 * m->nP + 8));
-  if (corner_boundary(m)) GPK_TRY(corner_stream_ensure());  // (before a capture starts)
+  if (corner_boundary(m)) GPK_TRY(corner_stream_ensure());
   m->hpin[2] = 0.0;
-  int rc = 0;
-  bool done = false;
-#ifndef GPK_HOSTSIM
-  // ---- launch graph: capture the enqueue once per (shape, buffers, schedule), replay it afterwards.  Only the
-  // hyper-parameters change between replays, and those are read from device memory (m->dse, rewritten below).
-  G.graph_fallback.clear();
-  const bool want_graph = G.graphs && !G.timing && !G.stamps && !m->keep_k && !m->k_only && !m->growable && G.lookahead && m->nP >= 3 && G.s_pred;
-  if (want_graph) {
-    std::vector<unsigned long long> key = {G.opt_epoch, (unsigned long long)m->N, (unsigned long long)m->d, (unsigned long long)m->Npad,
-                                           (unsigned long long)m->has_y, (unsigned long long)(uintptr_t)m->dX, (unsigned long long)(uintptr_t)m->dy,
-                                           (unsigned long long)(uintptr_t)m->dw, (unsigned long long)(uintptr_t)m->dK, (unsigned long long)(uintptr_t)m->dL,
-                                           (unsigned long long)(uintptr_t)m->dDinv, (unsigned long long)(uintptr_t)m->dscal, (unsigned long long)(uintptr_t)m->dws,
-                                           (unsigned long long)(uintptr_t)m->dinfo, (unsigned long long)(uintptr_t)m->dse, (unsigned long long)(uintptr_t)m->hpin,
-                                           (unsigned long long)(uintptr_t)g_cu_guest};
-    if (fp)
-      for (unsigned long long v : {(unsigned long long)fp->M, (unsigned long long)(uintptr_t)fp->dZ, (unsigned long long)(uintptr_t)fp->dR,
-                                   (unsigned long long)(uintptr_t)fp->dV, (unsigned long long)(uintptr_t)fp->dmean, (unsigned long long)(uintptr_t)fp->dvar})
-        key.push_back(v);
-    for (hipEvent_t e : m->ev) key.push_back((unsigned long long)(uintptr_t)e);  // (the captured waits name these events)
-    GPK_HIP(hipMemcpyAsync(m->dse, &m->se, sizeof(SEParams), hipMemcpyHostToDevice, s));
-    Runtime::GraphEntry* hit = nullptr;
-    for (auto& e : G.graph_cache)
-      if (e.key == key) hit = &e;
-    if (!hit) {
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
-      if (ce == hipSuccess) {
-        G.capturing = true;  // (a captured enqueue uses events only: a graph gives no launch-order guarantee a polling kernel could rely on)
-        const int erc = fit_enqueue(m, fp, m->dse);
-        G.capturing = false;
-        ce = hipStreamEndCapture(s, &graph);
-        if (erc != 0) {
-          G.graph_fallback = std::string("enqueue failed during capture: ") + gpk_err_cstr();
-          ce = hipErrorUnknown;
-        } else if (ce != hipSuccess || !graph) {
-          G.graph_fallback = std::string("hipStreamEndCapture: ") + hipGetErrorString(ce);
-          if (ce == hipSuccess) ce = hipErrorUnknown;
-        }
-        if (ce == hipSuccess) {
-          // (with or without hipGraphInstantiateFlagUseNodePriority: the same times, profiles/r03_launch_graph.txt)
-          ce = hipGraphInstantiateWithFlags(&exec, graph, hipGraphInstantiateFlagUseNodePriority);
-          if (ce != hipSuccess) G.graph_fallback = std::string("hipGraphInstantiate: ") + hipGetErrorString(ce);
-        }
-        if (graph) (void)hipGraphDestroy(graph);
-      } else {
-        G.graph_fallback = std::string("hipStreamBeginCapture: ") + hipGetErrorString(ce);
-      }
-      if (ce == hipSuccess && exec) {
-        if (G.graph_cache.size() >= 8) {  // least recently used out
-          size_t lru = 0;
-          for (size_t i = 1; i < G.graph_cache.size(); ++i)
-            if (G.graph_cache[i].last_use < G.graph_cache[lru].last_use) lru = i;
-          (void)hipGraphExecDestroy((hipGraphExec_t)G.graph_cache[lru].exec);
-          G.graph_cache.erase(G.graph_cache.begin() + lru);
-        }
-        G.graph_cache.push_back({key, (void*)exec, 0});
-        hit = &G.graph_cache.back();
-        G.graph_captures++;
-      } else {
-        (void)hipGetLastError();
-        // never silently: say once per process why this shape runs eagerly
-        static bool said = false;
-        if (!said) fprintf(stderr, "libgpk: launch-graph capture failed (%s); fits run eagerly\n", G.graph_fallback.c_str());
-        said = true;
-      }
-    }
-    if (hit) {
-      hit->last_use = ++G.graph_clock;
-      const auto host_t0 = std::chrono::steady_clock::now();
-      GPK_HIP(hipGraphLaunch((hipGraphExec_t)hit->exec, s));
-      G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-      G.last_pipe_enqueue_ms = 0.0;
-      G.graph_replays++;
-      g_potrf_lookahead_used = 1;
-      done = true;
-    }
-  }
-#endif
-  if (!done) rc = fit_enqueue(m, fp, nullptr);
+  int rc = fit_enqueue(m, fp);
   if (rc) {
     (void)hipStreamSynchronize(s);
     return rc;

@@ -126,16 +126,15 @@ struct SEParams {
 // mode 1: plain squared distance r2 (scaled by inv_ell, pass ones for raw)
 int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p,
                     int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0 = 0,
-                    const double* centre = nullptr, const SEParams* dparams = nullptr);
+                    const double* centre = nullptr);
 // centre (d doubles on the device): the point both sets are centred on in the dot-product form (d <= 8); nullptr = the
 // call's first column point.  Builds of one model in several calls pass the same centre (the same bits in every tile).
-// dparams: the hyper-parameters in device memory instead of by value (replayed launch graphs).
 
 // ---------------------------------------------------------------- aux kernels
 int launch_sum_log_diag(const double* Dinv, int N, double* out, hipStream_t s);              // -sum log Dinv_ii, i < N
 int launch_dot(const double* a, const double* b, int n, double* out, hipStream_t s);          // deterministic
 int launch_row_stats(const double* X, long ld, int rows, int n, const double* w, double sf2, double* mean,
-                     double* var, hipStream_t s, const double* sf2_dev = nullptr);  // mean_j = X_j . w ; var_j = sf2 - X_j . X_j
+                     double* var, hipStream_t s);  // mean_j = X_j . w ; var_j = sf2 - X_j . X_j
 // y = beta*y + alpha*A x  (one wave per row, coalesced);  gemv_sub: y -= A x
 int launch_gemv(const double* A, long lda, int m, int k, const double* x, double* y, double alpha, double beta, hipStream_t s);
 int launch_gemv_sub(const double* A, long lda, int m, int k, const double* x, double* y, hipStream_t s);

@@ -56,9 +56,8 @@ int launch_dot(const double* a, const double* b, int n, double* out, hipStream_t
 
 // one workgroup per row j of X (rows x n, ld): mean_j = X_j . w ; var_j = sf2 - X_j . X_j   (GPr.py:50-53)
 __global__ void row_stats_kernel(const double* __restrict__ X, long ld, int n, const double* __restrict__ w,
-                                 double sf2, const double* __restrict__ sf2_dev, double* mean, double* var) {
+                                 double sf2, double* mean, double* var) {
   __shared__ double sm[16];
-  if (sf2_dev) sf2 = *sf2_dev;  // (replayed launch graphs: the hyper-parameters live in device memory)
   const double* x = X + (long)blockIdx.x * ld;
   double a = 0.0, q = 0.0;
   for (int i = threadIdx.x * 2; i < n; i += blockDim.x * 2) {
@@ -74,9 +73,9 @@ __global__ void row_stats_kernel(const double* __restrict__ X, long ld, int n, c
   }
 }
 int launch_row_stats(const double* X, long ld, int rows, int n, const double* w, double sf2, double* mean,
-                     double* var, hipStream_t s, const double* sf2_dev) {
+                     double* var, hipStream_t s) {
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(row_stats_kernel, dim3(rows), dim3(256), 0, s, X, ld, n, w, sf2, sf2_dev, mean, var);
+  hipLaunchKernelGGL(row_stats_kernel, dim3(rows), dim3(256), 0, s, X, ld, n, w, sf2, mean, var);
   GPK_HIP(hipGetLastError());
   return 0;
 }

@@ -45,8 +45,7 @@ __device__ __forceinline__ double exp2_neg(double t) {
 // base-2 exponent, and log2(sf2) is folded into it: one add + exp2_neg per element instead of two multiplies + exp().
 template <int D, int MODE>  // D = 0: runtime dimension (column points re-read from LDS)
 __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict__ R, int nr,
-                                                       const double* __restrict__ Cc, int nc, SEParams pv,
-                                                       const SEParams* __restrict__ pd,
+                                                       const double* __restrict__ Cc, int nc, SEParams p,
                                                        int same_set, int lower_only,
                                                        double* __restrict__ out, long ld, int col_g0,
                                                        const double* __restrict__ centre) {
@@ -54,9 +53,6 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
   __shared__ double rs[128 * DMAX];
   __shared__ double cs[(D == 0) ? 128 * DMAX : 1];
   __shared__ double rn[128];  // squared norms of the (scaled) row points (mode 0, D != 0)
-  // hyper-parameters by value, or from device memory (pd): a captured launch graph is replayed with new
-  // hyper-parameters by rewriting that buffer, the launch itself stays what it was (gpk_core.hip: fit_device)
-  const SEParams& p = pd ? *pd : pv;
   const int d = (D == 0) ? p.d : D;
   int tc = blockIdx.x, tr = blockIdx.y;
   if (lower_only == 2) {  // 1-D grid over the lower triangle of tiles (no workgroups that only exit)
@@ -174,11 +170,11 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
 
 template <int MODE>
 static void se_build_dispatch(int dd, dim3 grid, dim3 block, hipStream_t s, const double* R, int nr, const double* Cc, int nc,
-                              const SEParams& p, const SEParams* pd, int same_set, int lo, double* out, long ld, int col_g0,
+                              const SEParams& p, int same_set, int lo, double* out, long ld, int col_g0,
                               const double* centre) {
 #define GPK_SE_CASE(DD)                                                                                                 \
   case DD:                                                                                                              \
-    hipLaunchKernelGGL((se_build_kernel<DD, MODE>), grid, block, 0, s, R, nr, Cc, nc, p, pd, same_set, lo, out, ld, col_g0, centre); \
+    hipLaunchKernelGGL((se_build_kernel<DD, MODE>), grid, block, 0, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0, centre); \
     break;
   switch (dd) {
     GPK_SE_CASE(1)
@@ -190,14 +186,13 @@ static void se_build_dispatch(int dd, dim3 grid, dim3 block, hipStream_t s, cons
     GPK_SE_CASE(7)
     GPK_SE_CASE(8)
     default:
-      hipLaunchKernelGGL((se_build_kernel<0, MODE>), grid, block, 0, s, R, nr, Cc, nc, p, pd, same_set, lo, out, ld, col_g0, centre);
+      hipLaunchKernelGGL((se_build_kernel<0, MODE>), grid, block, 0, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0, centre);
   }
 #undef GPK_SE_CASE
 }
 
 int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p,
-                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0, const double* centre,
-                    const SEParams* dparams) {
+                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0, const double* centre) {
   if (!centre) centre = Cc;  // the call's first column point
   if (nr_pad % 128 || nc_pad % 128 || (ld & 1) || ((uintptr_t)out & 15))
     return gpk_set_err(-1, "se_build: padded shape %dx%d ld %ld must be tile aligned", nr_pad, nc_pad, ld);
@@ -209,9 +204,9 @@ int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int n
     grid = dim3(nt * (nt + 1) / 2, 1);
     lo = 2;
   }
-  if (mode == 0) se_build_dispatch<0>(p.d, grid, block, s, R, nr, Cc, nc, p, dparams, same_set, lo, out, ld, col_g0, centre);
-  else if (mode == 1) se_build_dispatch<1>(p.d, grid, block, s, R, nr, Cc, nc, p, dparams, same_set, lo, out, ld, col_g0, centre);
-  else se_build_dispatch<2>(p.d, grid, block, s, R, nr, Cc, nc, p, dparams, same_set, lo, out, ld, col_g0, centre);
+  if (mode == 0) se_build_dispatch<0>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0, centre);
+  else if (mode == 1) se_build_dispatch<1>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0, centre);
+  else se_build_dispatch<2>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0, centre);
   GPK_HIP(hipGetLastError());
   return 0;
 }

@@ -36,17 +36,21 @@ int         gpk_init(int device);            /* bind this process to a GPU  */
 void        gpk_shutdown(void);
 const char* gpk_last_error(void);
 int         gpk_sync(void);                  /* hipDeviceSynchronize        */
-int         gpk_set_option(const char* key, double value); /* schedule switches: "nb", "lookahead", "gemm_pipe",
-                                                               "tail_rows", "leaf_server", ... (README.md); results do
-                                                               not depend on them beyond rounding, most not at all */
+int         gpk_set_option(const char* key, double value); /* schedule switches: "nb", "lookahead", "tail_rows",
+                                                               "pred_defer_from", "corner_from", "chain_fused", ...
+                                                               (README.md lists them); results do not depend on them
+                                                               beyond rounding, most not at all */
 double      gpk_get_option(const char* key);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */
 /* rank 0 calls gpk_comm_unique_id, the host broadcasts the 128 bytes by any
  * means (gptest_amd/dist.py: a plain TCP socket next to MASTER_PORT), every rank
- * calls gpk_comm_init.  A multi-rank process gives up the substitution stream
- * of the single-GPU pipeline (block-cyclic models never use it) for a
- * communication stream: the panel broadcasts run there, off the panel chain.
+ * calls gpk_comm_init.  A multi-rank process gets a communication stream: the
+ * panel broadcasts run there, off the panel chain; y and this rank's shard of
+ * the prediction are substituted on the substitution stream behind the
+ * per-panel "available" events (option "dist_pipeline", default 1; 0: three
+ * streams, prediction after the factorisation).  gpk_comm_destroy gives the
+ * process its single-GPU stream layout back.
  * Option "dist_group": panels per ownership block (default 2).              */
 int gpk_comm_unique_id(void* out128);
 int gpk_comm_init(int rank, int nranks, const void* uid128);

@@ -157,7 +157,7 @@ int launch_flag_set(unsigned* flag, unsigned v, hipStream_t) { *flag = v; return
 int launch_flag_probe(const unsigned* flag, unsigned want, unsigned* seen, hipStream_t) { (void)flag; (void)want; *seen = 1; return 0; }  // (the host simulation runs every stream in enqueue order)
 
 int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p, int same_set,
-                    int mode, double* out, long ld, long lower_only, hipStream_t, int col_g0, const double*, const SEParams*) {
+                    int mode, double* out, long ld, long lower_only, hipStream_t, int col_g0, const double*) {
   if (nr_pad % 128 || nc_pad % 128 || (ld & 1)) return gpk_set_err(-1, "se_build: padded shape must be tile aligned");
   if (p.d < 1 || p.d > 32) return gpk_set_err(-1, "se_build: input dimension d=%d outside 1..32", p.d);
   for (int tr = 0; tr < nr_pad / 128; ++tr)
@@ -196,7 +196,7 @@ int launch_dot(const double* a, const double* b, int n, double* out, hipStream_t
   *out = acc;
   return 0;
 }
-int launch_row_stats(const double* X, long ld, int rows, int n, const double* w, double sf2, double* mean, double* var, hipStream_t, const double*) {
+int launch_row_stats(const double* X, long ld, int rows, int n, const double* w, double sf2, double* mean, double* var, hipStream_t) {
   for (int r = 0; r < rows; ++r) {
     double a = 0.0, q = 0.0;
     for (int i = 0; i < n; ++i) { a += X[(long)r * ld + i] * w[i]; q += X[(long)r * ld + i] * X[(long)r * ld + i]; }

@@ -529,65 +529,6 @@ def test_deferred_far_updates_of_the_prediction_are_bitwise_the_immediate_ones(g
     np.testing.assert_allclose(v0, cov_o, rtol=RTOL, atol=RTOL * np.abs(cov_o).max())
 
 
-def test_launch_graph_replay_is_bitwise_the_eager_run(gpk):
-    """Option graphs (off by default: measured slower on this runtime): the multi-stream enqueue of a fit (+ fused prediction) is captured once per (shape,
-    buffers, schedule) and replayed; hyper-parameters reach the replayed launches through device memory.  Replays must
-    give the bits of the eager run -- also after the hyper-parameters changed -- a non-positive-definite K must surface the
-    same way, an optimiser-style sequence of fits (GP_regression_demo.py:44: one shape, new hyper-parameters every call)
-    must be served by at most a handful of captures, and nothing may fall back to eager silently."""
-    from gptest_amd import GPr
-    from oracle import gpr_oracle as orc
-
-    l = gpk.lib()
-    N, d, M = 1500, 3, 130
-    X, y, Z, lh = orc.synthetic_problem(N, d, M)
-    P = gpk.c_double_p
-    hyps = [lh, lh + 0.1, lh - np.array([0.2, 0.0, 0.1, 0.0, 0.3]), lh]
-
-    def posterior(h):
-        hc = np.ascontiguousarray(h)
-        ms, nl = ctypes.c_double(), ctypes.c_double()
-        mean, var = np.zeros(M), np.zeros(M)
-        rc = l.gpk_bench_posterior(_ptr(X), _ptr(y), N, d, _ptr(hc), _ptr(Z), M, 1, 2, ctypes.byref(ms), ctypes.byref(nl), _ptr(mean), _ptr(var))
-        assert rc == 0, gpk.last_error()
-        return nl.value, mean, var
-
-    gpk.set_option("graphs", 0)
-    eager = [posterior(h) for h in hyps]
-    gpk.set_option("graphs", 1)
-    c0, r0 = gpk.get_option("graph_captures"), gpk.get_option("graph_replays")
-    replay = [posterior(h) for h in hyps]
-    assert gpk.get_option("graph_fallback") == 0
-    assert gpk.get_option("graph_replays") - r0 == 3 * len(hyps)         # every fit of every call went through a graph
-    assert 1 <= gpk.get_option("graph_captures") - c0 <= len(hyps)         # ... and most of them through a cached one
-    for (n0, m0, v0), (n1, m1, v1) in zip(eager, replay):
-        assert n0 == n1 and np.array_equal(m0, m1) and np.array_equal(v0, v1)
-    nl_o, fz_o, cov_o = orc.posterior_efficient(lh, X, y, Z)
-    assert abs(replay[0][0] - nl_o) <= RTOL * abs(nl_o)
-    np.testing.assert_allclose(replay[0][1], fz_o, rtol=RTOL, atol=RTOL * np.abs(fz_o).max())
-    # the optimiser's call pattern through the Python surface: one shape, fresh model and new hyper-parameters per call
-    c1 = gpk.get_option("graph_captures")
-    gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", X, y)
-    vals = [gp.compute_likelihood(lh + 0.01 * k).flat[0] for k in range(12)]
-    assert gpk.get_option("graph_captures") - c1 <= 3, gpk.get_option("graph_captures") - c1
-    gpk.set_option("graphs", 0)
-    gp2 = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", X, y)
-    vals2 = [gp2.compute_likelihood(lh + 0.01 * k).flat[0] for k in range(12)]
-    assert vals == vals2
-    gpk.set_option("graphs", 1)
-    assert gpk.get_option("graph_fallback") == 0
-    # not positive definite under replay: same LAPACK-style report as eager
-    Xd = X.copy()
-    Xd[700] = Xd[650]
-    lh0 = lh.copy()
-    lh0[-1] = -np.inf
-    for rep in range(2):
-        gpd = GPr.GaussianProcess(lh0, 0, 0, "SE", "zero", "zero", Xd, y)
-        with pytest.raises(np.linalg.LinAlgError):
-            gpd.compute_likelihood(lh0)
-
-
-# ----------------------------------------------------------------------------- golden vectors (real reference)
 @pytest.mark.parametrize("case", golden_cases())
 def test_gpr_dropin_matches_reference_golden(gpk, case):
     from gptest_amd import GPr
@@ -865,10 +806,21 @@ def test_block_cyclic_posterior_emulated_ranks(gpk, N, d, M, P, nb, group):
                                            _ptr(nl), _ptr(mean), _ptr(var))
     assert rc == 0, gpk.last_error()
     assert gpk.get_option("dist_lookahead_used") == 1
+    assert gpk.get_option("dist_pipelined") == 1  # y and every rank's shard of the prediction substituted behind the panel events
     for r in range(1, P):
         assert nl[r] == nl[0]
         np.testing.assert_array_equal(mean[r], mean[0])
         np.testing.assert_array_equal(var[r], var[0])
+    # ... which gives the very bits of the fit followed by the separate sharded prediction (options dist_pipeline / fuse_predict = 0)
+    for key in ("dist_pipeline", "fuse_predict"):
+        gpk.set_option(key, 0)
+        nl2, mean2, var2 = np.zeros(P), np.zeros((P, M)), np.zeros((P, M))
+        rc = hooks().gpk_test_dist_posterior(_ptr(X), _ptr(y), N, d, _ptr(np.ascontiguousarray(lh)), _ptr(Z), M, P,
+                                               _ptr(nl2), _ptr(mean2), _ptr(var2))
+        assert rc == 0, gpk.last_error()
+        assert gpk.get_option("dist_pipelined") == 0
+        assert np.array_equal(nl2, nl) and np.array_equal(mean2, mean) and np.array_equal(var2, var), key
+        gpk.set_option(key, 1)
     gp = GPr.GaussianProcess(lh, 0, 0, "SE", "zero", "zero", X, y)
     nl1 = gp.compute_likelihood(lh)[0, 0]
     f1, c1 = gp.compute_prediction(Z)
