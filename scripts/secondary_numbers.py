@@ -51,4 +51,12 @@ for rep in range(2):
     t = time.perf_counter() - t0
 print("preference Laplace loop, 8192 pairs (nx = 16384), d = 4: %.1f ms, %d Newton iterations, converged %s, lml %.6f"
       % (t * 1e3, gp.last_iterations, gp.last_converged, lml), flush=True)
+# accounting (BASELINE config 5): one Cholesky of K + eps I at nx (nx^3 / 3 flops) and, per Newton iteration, one of
+# B = I + C^1/2 (D K D^T) C^1/2 at npairs, two GEMVs with the kept copy of K (8 nx^2 bytes each) and the build of B (16 npairs^2 bytes)
+nx = 2 * npairs
+flop = nx ** 3 / 3.0 + gp.last_iterations * npairs ** 3 / 3.0
+byts = gp.last_iterations * (2 * 8.0 * nx * nx + 16.0 * npairs * npairs)
+print("   accounting: %.2f Tflop of fp64 MFMA work (K: %.2f, %d x B: %.2f each) -> %.1f TFLOP/s = %.2f of 78.6 over the loop; %.1f GB of GEMV / build-B "
+      "traffic = %.2f ms at 8 TB/s.  Both factorisations are chain-bound sizes (Npad = 16384 once, 8192 per iteration: 7.9-8.3 ms each alone)"
+      % (flop / 1e12, nx ** 3 / 3.0 / 1e12, gp.last_iterations, npairs ** 3 / 3.0 / 1e12, flop / t / 1e12, flop / t / 78.6e12, byts / 1e9, byts / 8e12 * 1e3), flush=True)
 _lib.shutdown()

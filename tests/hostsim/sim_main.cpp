@@ -74,6 +74,12 @@ int main() {
   opt("nb", 128); opt("tail_rows", 1 << 30);
   check_fit_predict(make_problem(900, 3, 20), "tile pipeline for the whole factorisation");
   CHECK(gpk_get_option("potrf_tail_from") == 0, "tile pipeline from panel 0");
+  for (int cf : {1, 2}) {  // one launch per chain step (flags set / polled across streams; the stand-ins check the producer came first)
+    opt("chain_fused", cf);
+    check_fit_predict(make_problem(900, 3, 20), "tile pipeline with the fused chain step");
+    CHECK(gpk_get_option("potrf_chain_fused") == 7, "fused chain steps: %g", gpk_get_option("potrf_chain_fused"));
+  }
+  opt("chain_fused", 0);
   check_fit_predict(make_problem(300, 1, 5), "tile pipeline, three tiles");
   opt("tail_rows", 0); opt("nb", 0);
   opt("nb_outer", 2048); opt("outer_until", 8192); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
