@@ -148,6 +148,11 @@ int gpk_set_option(const char* key, double value) {
   } else if (k == "dist_group") {
     if (v < 1 || v > 64) return gpk_set_err(-1, "dist_group must be in 1..64");
     G.dist_group = v;
+  } else if (k == "dist_tail") {
+    G.dist_tail = v ? 1 : 0;
+  } else if (k == "dist_tail_chunk") {
+    if (v < 1 || v > 64) return gpk_set_err(-1, "gpk_set_option: dist_tail_chunk must be 1..64");
+    G.dist_tail_chunk = (int)v;
   } else if (k == "dist_pipeline") {
     G.dist_pipeline = v ? 1 : 0;
   } else if (k == "tail_rows") {
@@ -211,6 +216,10 @@ double gpk_get_option(const char* key) {
   if (k == "lookahead") return G.lookahead;
   if (k == "dist_group") return G.dist_group;
   if (k == "dist_pipeline") return G.dist_pipeline;
+  if (k == "dist_tail") return G.dist_tail;
+  if (k == "dist_tail_chunk") return G.dist_tail_chunk;
+  if (k == "dist_tail_from") return g_dist_tail_from;
+  if (k == "dist_tail_col") return g_dist_tail_col;
   if (k == "tail_rows") return G.tail_rows;
   if (k == "leaf_fat_rows") return G.leaf_fat_rows;
   if (k == "gemm_polite") { extern int g_gemm_polite; return g_gemm_polite; }

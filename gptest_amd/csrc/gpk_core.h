@@ -41,6 +41,8 @@ struct Runtime {
   int nb_outer = 2048, outer_until = 8192;
   int lookahead = 1;
   int dist_group = 2;   // panels (of the middle width) per ownership block of a block-cyclic (multi-GPU) model
+  int dist_tail = 1;      // block-cyclic models: the last tail_rows columns as one tail block on one rank, factored there by the tile pipeline
+  int dist_tail_chunk = 8; // ... whose panels are broadcast this many at a time
   int dist_pipeline = 1;  // multi-rank process: keep the substitution stream next to the communication stream and pipeline y / this rank's
                           // shard of the prediction behind the per-panel "available" events (fit_group_impl); 0: three streams, prediction afterwards
   // tile pipeline (potrf_tail) for the chain-bound last tail_rows columns (needs 128-wide panels there: nb_small_from);
@@ -136,16 +138,42 @@ struct gpk_model {
   // local block b / P), so that inside a group the next panel's owner already holds the panel it needs and no
   // broadcast sits on the panel chain; nloc = number of local ownership blocks, ldk = nloc * OB.  P == 1: OB = Npad.
   int OB = 0;
-  int owner_of_col(long c) const { return P > 1 ? (int)((c / OB) % P) : 0; }
-  long local_col(long c) const { return P > 1 ? (c / OB / P) * OB + c % OB : c; }   // c must be owned
+  // Tail block (round 4): from global column ct on (an ownership-block boundary; 0: none) every column belongs to ONE rank, t_own --
+  // the chain-bound last columns then run through the one-GPU tile pipeline on that rank (no hand-over inside the tail is a
+  // broadcast; its panels are broadcast behind the chain).  Local layout of a rank: its nloc_c cyclic blocks of the columns
+  // below ct side by side, then (on t_own only) the Npad - ct tail columns.
+  int ct = 0, t_own = 0, nloc_c = 0, p_tail = 0;  // p_tail: the panel that starts at ct
+  int owner_of_col(long c) const {
+    if (ct > 0 && c >= ct) return t_own;
+    return P > 1 ? (int)((c / OB) % P) : 0;
+  }
+  long local_col(long c) const {  // c must be owned
+    if (ct > 0 && c >= ct) return (long)nloc_c * OB + (c - ct);
+    return P > 1 ? (c / OB / P) * OB + c % OB : c;
+  }
   long local_from(long c) const {  // first local column whose global column is >= c (ldk if none)
-    if (P == 1) return c;
+    if (P == 1 && ct == 0) return c;
     if (c >= Npad) return ldk;
+    if (ct > 0 && c >= ct) return r == t_own ? (long)nloc_c * OB + (c - ct) : ldk;
+    const long nb_all = (ct > 0 ? ct : Npad) / OB;  // cyclic blocks
     const long b = c / OB;
     if ((int)(b % P) == r) return (b / P) * OB + c % OB;
     long nb_ = b + 1;
-    while ((int)(nb_ % P) != r) ++nb_;
-    return std::min<long>(ldk, (nb_ / P) * OB);
+    while (nb_ < nb_all && (int)(nb_ % P) != r) ++nb_;
+    if (nb_ < nb_all) return (nb_ / P) * OB;
+    return (ct > 0 && r == t_own) ? (long)nloc_c * OB : ldk;  // no cyclic block left: the tail block (its owner) or nothing
+  }
+  // the global column ranges this rank stores, in local order: (first global column, columns, first local column)
+  struct ColRange { int gc0, ncols; long lc0; };
+  std::vector<ColRange> owned_ranges() const {
+    std::vector<ColRange> v;
+    if (P == 1 && ct == 0) { v.push_back({0, Npad, 0}); return v; }
+    const int nb_all = (ct > 0 ? ct : Npad) / OB;
+    int lb = 0;
+    for (int b = 0; b < nb_all; ++b)
+      if (b % P == r) { v.push_back({b * OB, OB, (long)lb * OB}); ++lb; }
+    if (ct > 0 && r == t_own) v.push_back({ct, Npad - ct, (long)nloc_c * OB});
+    return v;
   }
   bool virtual_rank = false;  // single-process emulation of rank r of P (tests): no RCCL calls
   // virtual ranks only: the P rank models of the emulated job, indexed by rank.  The "broadcast" / "all-gather" of a
@@ -221,6 +249,8 @@ int fit_group(gpk_model* const* ms, int n);
 int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var);
 // fit + sharded prediction in one go: the y and prediction substitutions pipelined behind the per-panel events of the block-cyclic factorisation
 int fit_predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var);
+extern int g_dist_tail_from;        // first panel the last block-cyclic factorisation ran through the tile pipeline on the tail's owner (-1: none)
+extern int g_dist_tail_col;         // ... and its first column
 extern int g_dist_pipelined;        // 1 if the last block-cyclic fit queued its substitutions behind the panel events
 int build_K(gpk_model* m);                                      // dX -> dK (local block columns)
 int factor_panel(gpk_model* m, int p, hipStream_t s);          // owner only

@@ -197,10 +197,25 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   m->nO = (int)m->oc0.size();
   m->nP = (int)m->pc0.size();
   m->L_elems = off;
+  // block-cyclic models: the chain-bound last columns as ONE tail block on one rank (gpk_model::ct), so that the tile pipeline can
+  // run there (dist_tail_phase).  From the first 128-wide panel that starts an ownership block with at most tail_rows rows left.
+  m->ct = 0;
+  if (P > 1 && !growable && G.lookahead && G.tail_rows > 0 && G.dist_tail) {
+    for (int p = 1; p < m->nP; ++p) {
+      if (m->pw[p] != 128 || m->pc0[p] % m->OB || m->Npad - m->pc0[p] > G.tail_rows) continue;
+      bool all128 = true;
+      for (int q = p; q < m->nP; ++q) all128 = all128 && m->pw[q] == 128 && m->pld[q] == 128;
+      if (all128 && m->nP - p >= 4) { m->ct = m->pc0[p]; m->p_tail = p; }
+      break;
+    }
+  }
+  m->t_own = m->ct > 0 ? (m->ct / m->OB) % P : 0;
   m->nloc = 0;
-  for (int b = 0; b < m->Npad / m->OB; ++b)
+  for (int b = 0; b < (m->ct > 0 ? m->ct : m->Npad) / m->OB; ++b)
     if (b % P == r) m->nloc++;
-  m->ldk = (P > 1) ? (long)std::max(m->nloc, 1) * m->OB : (long)m->Npad;
+  m->nloc_c = m->nloc;
+  m->ldk = (P > 1) ? (long)m->nloc * m->OB + ((m->ct > 0 && r == m->t_own) ? m->Npad - m->ct : 0) : (long)m->Npad;
+  if (m->ldk < m->OB) m->ldk = m->OB;
   m->keep_k = keep_k;
   const size_t np = m->Npad;
   int rc = 0;
@@ -323,7 +338,7 @@ int panel_update(gpk_model* m, int p, int r0g, int c0g, int ncols, int lower, hi
   GemmNT g{};
   g.A = Lp + (long)(r0g - c0) * ld; g.lda = ld;
   g.B = Lp + (long)(c0g - c0) * ld; g.ldb = ld;
-  g.C = m->dK + (long)r0g * m->ldk + c0g; g.ldc = m->ldk;
+  g.C = m->dK + (long)r0g * m->ldk + m->local_col(c0g); g.ldc = m->ldk;
   g.m = rows; g.n = ncols; g.k = w; g.sub = 1; g.lower = lower;
   // Few 128x128 tiles = a latency-bound launch on the panel chain (look-ahead block column, tail of the
   // factorisation): 64x64 tiles put 4x as many CUs on it (84 tiles at K = 256: 70 us -> 64x64: ~20 us).
@@ -342,7 +357,7 @@ int outer_update(gpk_model* m, int o, int r0g, int c0g, int ncols, int lower, hi
   GemmNT g{};
   g.A = Lo + (long)(r0g - c0) * W; g.lda = W;
   g.B = Lo + (long)(c0g - c0) * W; g.ldb = W;
-  g.C = m->dK + (long)r0g * m->ldk + c0g; g.ldc = m->ldk;
+  g.C = m->dK + (long)r0g * m->ldk + m->local_col(c0g); g.ldc = m->ldk;
   g.m = rows; g.n = ncols; g.k = W; g.sub = 1; g.lower = lower;
   const long nc = ncols / 128, nr = rows / 128;
   const long tiles = lower ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc;
@@ -358,9 +373,27 @@ int dist_update(gpk_model* m, int p, long gc_lo, long gc_hi, hipStream_t s) {
   const int r0 = c0 + w;
   const int rows = np_ - r0;
   if (gc_lo < r0) gc_lo = r0;
-  const long lc_lo = m->local_from(gc_lo), lc_hi = m->local_from(gc_hi);
-  if (rows <= 0 || lc_hi <= lc_lo) return 0;
+  if (gc_hi > np_) gc_hi = np_;
+  if (rows <= 0 || gc_hi <= gc_lo) return 0;
   double* Lp = m->Lpanel(p);
+  if (m->ct > 0 && gc_hi > m->ct) {
+    // the tail block (its owner only): a plain lower update from (cs, cs) -- rows above cs are above the diagonal of these columns
+    if (m->r == m->t_own) {
+      const long cs = std::max<long>(gc_lo, m->ct);
+      const long nt = (np_ - cs) / 128, nc = (gc_hi - cs) / 128;
+      GemmNT g{};
+      g.A = Lp + (cs - c0) * m->pld[p]; g.lda = m->pld[p];
+      g.B = g.A; g.ldb = g.lda;
+      g.C = m->dK + cs * m->ldk + m->local_col(cs); g.ldc = m->ldk;
+      g.m = (int)(np_ - cs); g.n = (int)(gc_hi - cs); g.k = w; g.sub = 1; g.lower = 1;
+      if (nc * (nc + 1) / 2 + (nt - nc) * nc < G.small_tile_below) GPK_TRY(launch_gemm_nt(g, false, s));
+      else GPK_TRY(launch_gemm_auto(g, s));
+    }
+    gc_hi = m->ct;
+    if (gc_hi <= gc_lo) return 0;
+  }
+  const long lc_lo = m->local_from(gc_lo), lc_hi = m->local_from(gc_hi);
+  if (lc_hi <= lc_lo) return 0;
   GemmNT g{};
   g.A = Lp + (long)w * m->pld[p]; g.lda = m->pld[p];
   g.B = g.A; g.ldb = g.lda;
@@ -524,7 +557,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
     const int c0 = m->pc0[p], h = np_ - c0;
     const long ld = m->pld[p];
     double* Lp = m->Lpanel(p);
-    double* Acol = m->dK + (long)c0 * ldk + c0;
+    double* Acol = m->dK + (long)c0 * ldk + m->local_col(c0);  // (tile (p,p); the tail columns are contiguous in local storage too)
     double* Dt = m->dDinv + (long)(c0 / 128) * 128 * 128;
     // ---- critical stream.  One event per step: `tt` after the two one-tile GEMMs (or `leaf` for the last tile, which has
     // none): an event packet on the chain stream costs ~5 us of a ~85 us step, and the full-height solve is never what the
@@ -727,7 +760,7 @@ static int span_update(gpk_model* m, int o_first, int o_last, int r0g, int c0g, 
     q.k = W;
   }
   GemmNT g{};
-  g.C = m->dK + (long)r0g * m->ldk + c0g; g.ldc = m->ldk;
+  g.C = m->dK + (long)r0g * m->ldk + m->local_col(c0g); g.ldc = m->ldk;
   g.m = rows; g.n = ncols; g.sub = 1; g.lower = lower;
   unsigned* ctr = nullptr;
   if (persist_grid > 0 && G.dctr) ctr = G.dctr + (G.dctr_next++ & 63);
@@ -969,7 +1002,7 @@ static int dist_publish_panel(gpk_model* m, int p) {
 static int dist_la_begin(gpk_model* m) {
   hipStream_t sm = G.s_main, sp = G.s_panel, sc = comm_stream();
   const int nP = m->nP;
-  GPK_TRY(model_events(m, 3 * nP + 8));
+  GPK_TRY(model_events(m, 10 * nP + 8));  // (the tail's tile pipeline uses the one-GPU event slots)
   GPK_HIP(hipMemsetAsync(m->dinfo, 0, 16, sm));
   GPK_HIP(hipEventRecord(m->ev[2 * nP], sm));  // nothing may start before the K build queued on s_main
   GPK_HIP(hipStreamWaitEvent(sp, m->ev[2 * nP], 0));
@@ -1007,6 +1040,68 @@ static int dist_la_update_phase(gpk_model* m, int p) {
   GPK_HIP(hipEventRecord(ev_trail[p], sm));
   return 0;
 }
+// panels [q0, q1) of the tail block in one broadcast each for L and Dinv: 128-wide panels, each an outer panel of its own, lie back to back
+static int bcast_tail_panels(gpk_model* m, int q0, int q1, hipStream_t s) {
+  const int owner = m->t_own;
+  const size_t off = m->poff[q0], cnt = (q1 < m->nP ? m->poff[q1] : m->L_elems) - off;
+  const size_t doff = (size_t)(m->pc0[q0] / 128) * 128 * 128, dcnt = (size_t)(q1 - q0) * 128 * 128;
+  if (m->virtual_rank) {
+    if (!m->vgroup) return gpk_set_err(-1, "internal: virtual rank %d without a group", m->r);
+    if (owner == m->r) return 0;
+    const gpk_model* o = m->vgroup[owner];  // the caller has made `s` wait for the owner's panel q1 - 1
+    GPK_HIP(hipMemcpyAsync(m->dL + off, o->dL + off, cnt * 8, hipMemcpyDeviceToDevice, s));
+    GPK_HIP(hipMemcpyAsync(m->dDinv + doff, o->dDinv + doff, dcnt * 8, hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
+  GPK_TRY(comm_bcast(m->dL + off, cnt, owner, s));
+  GPK_TRY(comm_bcast(m->dDinv + doff, dcnt, owner, s));
+  return 0;
+}
+// ---- the tail block (gpk_model::ct): hand-over from the cyclic part and the tile pipeline on the tail's owner.  Panel p = p_tail - 1 is the
+//      last cyclic panel; its update touches tail columns only.  Owner: three tile columns on the chain stream, the rest on the update
+//      stream, then potrf_tail over the tail's panels, each of which is broadcast (communication stream) once all of its rows are in
+//      place.  Everybody else: receives the tail's panels in order.
+int g_dist_tail_from = -1, g_dist_tail_col = -1;
+static int dist_tail_phase(gpk_model* m) {
+  hipStream_t sm = G.s_main, sp = G.s_panel, sc = comm_stream();
+  const int nP = m->nP, pt = m->p_tail, p = pt - 1, np_ = m->Npad;
+  hipEvent_t* ev_avail = m->ev.data();
+  hipEvent_t* ev_trail = m->ev.data() + nP;
+  hipEvent_t* ev_bcast = m->ev.data() + 2 * nP + 6;
+  // the tail's panels travel dist_tail_chunk at a time (the same chunks on every rank): one collective launch per chunk next to the
+  // owner's chain instead of two per panel; a chunk's panels become available together
+  const int chunk = std::max(1, G.dist_tail_chunk);
+  if (m->r != m->t_own) {
+    for (int q0 = pt; q0 < nP; q0 += chunk) {
+      const int q1 = std::min(nP, q0 + chunk);
+      if (m->virtual_rank) GPK_HIP(hipStreamWaitEvent(sc, m->vgroup[m->t_own]->ev[q1 - 1], 0));
+      GPK_TRY(bcast_tail_panels(m, q0, q1, sc));
+      for (int q = q0; q < q1; ++q) {
+        GPK_HIP(hipEventRecord(ev_bcast[q], sc));
+        GPK_HIP(hipEventRecord(ev_avail[q], sc));
+      }
+    }
+    return 0;
+  }
+  const int w_la = std::min(384, np_ - m->ct);
+  if (p > 0) GPK_HIP(hipStreamWaitEvent(sp, ev_trail[p - 1], 0));  // earlier updates of the tail columns ran on s_main
+  GPK_HIP(hipStreamWaitEvent(sp, ev_avail[p], 0));
+  GPK_TRY(dist_update(m, p, m->ct, m->ct + w_la, sp));
+  GPK_HIP(hipStreamWaitEvent(sm, ev_avail[p], 0));
+  timer_begin("trailing", sm, dist_update_flops(m, p, m->ct + w_la, np_));
+  GPK_TRY(dist_update(m, p, m->ct + w_la, np_, sm));
+  timer_end("trailing", sm);
+  GPK_HIP(hipEventRecord(ev_trail[p], sm));
+  std::function<int(int)> publish = [&](int q) -> int {  // panel q is complete on this rank (potrf_tail: ev[q] recorded on s_main)
+    const int q0 = pt + (q - pt) / chunk * chunk, q1 = std::min(nP, q0 + chunk);
+    if (q + 1 < q1) return 0;
+    GPK_HIP(hipStreamWaitEvent(sc, ev_avail[q], 0));
+    GPK_TRY(bcast_tail_panels(m, q0, q1, sc));
+    for (int k = q0; k < q1; ++k) GPK_HIP(hipEventRecord(ev_bcast[k], sc));
+    return 0;
+  };
+  return potrf_tail(m, pt, ev_trail[p], &publish);
+}
 static int dist_la_end(gpk_model* m) {
   // everything after potrf runs on s_main: the last panel must be here and the communication stream drained
   GPK_HIP(hipStreamWaitEvent(G.s_main, m->ev[m->nP - 1], 0));
@@ -1039,7 +1134,7 @@ int potrf_group(gpk_model* const* ms, int n) {
   const int nP = ms[0]->nP, P = ms[0]->P;
   for (int i = 0; i < n; ++i) {
     const gpk_model* m = ms[i];
-    if (m->P != P || m->nP != nP || m->Npad != ms[0]->Npad || m->OB != ms[0]->OB)
+    if (m->P != P || m->nP != nP || m->Npad != ms[0]->Npad || m->OB != ms[0]->OB || m->ct != ms[0]->ct)
       return gpk_set_err(-1, "potrf_group: rank models disagree on the block-cyclic layout");
     if (n > 1 && (!m->virtual_rank || n != P || m->r != i || m->vgroup != ms))
       return gpk_set_err(-1, "potrf_group: a group of %d needs the %d virtual ranks in rank order", n, P);
@@ -1059,7 +1154,14 @@ int potrf_group(gpk_model* const* ms, int n) {
     return 0;
   }
   GPK_TRY(from_owner(0, [&](gpk_model* m) { return dist_la_begin(m); }));
+  const int p_tail = ms[0]->ct > 0 ? ms[0]->p_tail : nP;  // from here on: the tail block, one rank's tile pipeline
+  g_dist_tail_from = p_tail < nP ? p_tail : -1;
+  g_dist_tail_col = p_tail < nP ? ms[0]->ct : -1;
   for (int p = 0; p < nP; ++p) {
+    if (p_tail < nP && p + 1 == p_tail) {
+      GPK_TRY(from_owner(ms[0]->t_own, [&](gpk_model* m) { return dist_tail_phase(m); }));
+      break;
+    }
     GPK_TRY(from_owner(p + 1 < nP ? panel_owner(ms[0], p + 1) : 0, [&](gpk_model* m) { return dist_la_panel_phase(m, p); }));
     GPK_TRY(from_owner(0, [&](gpk_model* m) { return dist_la_update_phase(m, p); }));
   }
@@ -1073,14 +1175,13 @@ int build_K(gpk_model* m) {
   const int np_ = m->Npad;
   if (m->P == 1)
     return launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s);
-  for (int lb = 0; lb < m->nloc; ++lb) {  // one launch per owned ownership block
-    const int cg0 = (lb * m->P + m->r) * m->OB;
-    int nc = m->N - cg0;
-    if (nc > m->OB) nc = m->OB;
+  for (const gpk_model::ColRange& cr : m->owned_ranges()) {  // one launch per owned block (cyclic blocks, then the tail block on its owner)
+    int nc = m->N - cr.gc0;
+    if (nc > cr.ncols) nc = cr.ncols;
     if (nc < 0) nc = 0;
     // column points of this block (clamped pointer: nc == 0 blocks are pure padding)
-    const double* Cc = m->dX + (size_t)(nc > 0 ? cg0 : 0) * m->d;
-    GPK_TRY(launch_se_build(m->dX, m->N, np_, Cc, nc, m->OB, m->se, 1, 0, m->dK + (size_t)lb * m->OB, m->ldk, 1, s, cg0, m->dX));
+    const double* Cc = m->dX + (size_t)(nc > 0 ? cr.gc0 : 0) * m->d;
+    GPK_TRY(launch_se_build(m->dX, m->N, np_, Cc, nc, cr.ncols, m->se, 1, 0, m->dK + cr.lc0, m->ldk, 1, s, cr.gc0, m->dX));
   }
   return 0;
 }

@@ -12,14 +12,6 @@
 const char* gpk_err_cstr();
 
 // ---------------------------------------------------------------- kernel-level test hooks
-__global__ void pad_diag_local_kernel(double* K, long ldk, int N, int Npad, int OB, int P, int r) {
-  // ones on the padded diagonal entries (i >= N) that fall into this rank's ownership blocks (width OB)
-  for (int i = N + blockIdx.x * blockDim.x + threadIdx.x; i < Npad; i += gridDim.x * blockDim.x) {
-    const int g = i / OB;
-    if (g % P == r) K[(long)i * ldk + (long)(g / P) * OB + (i % OB)] = 1.0;
-  }
-}
-
 extern "C" {
 
 // Single-GPU emulation of a P-rank block-cyclic job: P rank models live in this process and are driven through
@@ -60,7 +52,7 @@ int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
   hipStream_t s = G.s_main;
   VirtualJob job;
   GPK_TRY(job.create(N, 1, P));
-  const int OB = job.ms[0]->OB, np_ = job.ms[0]->Npad;
+  const int np_ = job.ms[0]->Npad;
   for (int r = 0; r < P; ++r) {
     gpk_model* m = job.ms[r];
     GPK_HIP(hipMemsetAsync(m->dK, 0, (size_t)np_ * m->ldk * 8, s));
@@ -69,14 +61,13 @@ int gpk_test_dist_potrf(const double* A, int N, int P, double* L_out) {
       if (np_ > N) GPK_TRY(launch_pad_identity(m->dK, m->ldk, N, np_, s));
       continue;
     }
-    for (int lb = 0; lb < m->nloc; ++lb) {
-      const int cg0 = (lb * P + r) * OB;
-      const int nc = std::min(OB, N - cg0);
-      if (nc <= 0) continue;
-      GPK_HIP(hipMemcpy2DAsync(m->dK + (size_t)lb * OB, (size_t)m->ldk * 8, A + cg0, (size_t)N * 8, (size_t)nc * 8, N,
-                               hipMemcpyHostToDevice, s));
+    for (const gpk_model::ColRange& cr : m->owned_ranges()) {  // the rank's block columns of A (cyclic blocks, then the tail block on its owner)
+      const int nc = std::min(cr.ncols, N - cr.gc0);
+      if (nc > 0)
+        GPK_HIP(hipMemcpy2DAsync(m->dK + cr.lc0, (size_t)m->ldk * 8, A + cr.gc0, (size_t)N * 8, (size_t)nc * 8, N, hipMemcpyHostToDevice, s));
+      const int g0 = std::max(N, cr.gc0), cnt = cr.gc0 + cr.ncols - g0;  // ones on the padded diagonal entries of this block
+      if (cnt > 0) GPK_TRY(launch_set_diag(m->dK + (size_t)g0 * m->ldk + cr.lc0 + (g0 - cr.gc0), m->ldk, cnt, 1.0, s));
     }
-    if (np_ > N) hipLaunchKernelGGL(pad_diag_local_kernel, dim3(8), dim3(256), 0, s, m->dK, m->ldk, N, np_, OB, P, r);
   }
   GPK_TRY(P == 1 ? potrf_device(job.ms[0]) : potrf_group(job.ms.data(), P));
   GPK_TRY(virtual_job_check_info(job, N));

@@ -24,14 +24,18 @@ def env_rank():
     return rank, local, world
 
 
-def block_cyclic_owner(block, world):
-    """Owner rank of outer block column ``block`` (1-D block-cyclic)."""
+def block_cyclic_owner(block, world, tail_from=None):
+    """Owner rank of ownership block ``block`` (1-D block-cyclic).  Blocks from ``tail_from`` on form the
+    tail block, which belongs as a whole to the rank that owns block ``tail_from`` (gpk_model::ct in
+    gptest_amd/csrc/gpk_core.h: the chain-bound last columns are factored by one rank's tile pipeline)."""
+    if tail_from is not None and block >= tail_from:
+        block = tail_from
     return block % world
 
 
-def local_blocks(rank, world, nblocks):
+def local_blocks(rank, world, nblocks, tail_from=None):
     """Global block-column indices owned by ``rank``."""
-    return list(range(rank, nblocks, world))
+    return [b for b in range(nblocks) if block_cyclic_owner(b, world, tail_from) == rank]
 
 
 def torch_bootstrap(payload):

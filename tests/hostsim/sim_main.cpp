@@ -161,6 +161,41 @@ int main() {
     }
   }
   opt("lookahead", 1);
+  // ---- the tail block: the last tail_rows columns live on one rank, which runs the tile pipeline over them and broadcasts its panels
+  for (int grp : {1, 2, 3}) for (int fused : {0, 2}) {
+    opt("dist_group", grp); opt("nb", 128); opt("tail_rows", 768); opt("chain_fused", fused); opt("dist_tail_chunk", fused ? 4 : 1);
+    const int N = 1700;
+    vec A((size_t)N * N);
+    for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) { const double v = (i == j ? N + 1.0 : 0.0) + std::cos(0.1 * (i - j)); A[(size_t)i * N + j] = A[(size_t)j * N + i] = v; }
+    vec L1((size_t)N * N), LP((size_t)N * N), L0((size_t)N * N);
+    CHECK(gpk_test_dist_potrf(A.data(), N, 1, L1.data()) == 0, "tail block P=1");
+    for (int P : {2, 3, 4, 8}) {
+      opt("dist_tail", 1);
+      CHECK(gpk_test_dist_potrf(A.data(), N, P, LP.data()) == 0, "tail block P=%d", P);
+      CHECK(gpk_get_option("dist_tail_from") > 0, "tail block used P=%d group=%d: %g", P, grp, gpk_get_option("dist_tail_from"));
+      CHECK(maxdiff(L1, LP) == 0.0, "tail block P=%d group=%d diff %g", P, grp, maxdiff(L1, LP));
+      opt("dist_tail", 0);
+      CHECK(gpk_test_dist_potrf(A.data(), N, P, L0.data()) == 0, "no tail block P=%d", P);
+      CHECK(gpk_get_option("dist_tail_from") < 0, "tail block off P=%d", P);
+      CHECK(maxdiff(L0, LP) == 0.0, "tail block on/off P=%d group=%d diff %g", P, grp, maxdiff(L0, LP));
+    }
+    opt("dist_tail", 1); opt("chain_fused", 0); opt("dist_tail_chunk", 8);
+  }
+  {
+    Problem p = make_problem(1500, 3, 70);
+    const Posterior ref = dense_posterior(p, p.N);
+    opt("dist_group", 1); opt("nb", 128); opt("tail_rows", 640);
+    for (int P : {2, 3}) {
+      vec nl(P), mean((size_t)P * p.M), var((size_t)P * p.M);
+      CHECK(gpk_test_dist_posterior(p.X.data(), p.y.data(), p.N, p.d, p.lh.data(), p.Z.data(), p.M, P, nl.data(), mean.data(), var.data()) == 0, "tail-block posterior P=%d", P);
+      CHECK(gpk_get_option("dist_tail_from") > 0, "tail block used in the posterior P=%d", P);
+      for (int r = 0; r < P; ++r) {
+        CHECK(std::fabs(nl[r] - ref.nlml) <= 1e-9 * std::fabs(ref.nlml), "tail-block posterior nlml rank %d", r);
+        CHECK(maxdiff(vec(mean.begin() + (size_t)r * p.M, mean.begin() + (size_t)(r + 1) * p.M), ref.mean) <= 1e-8, "tail-block mean rank %d", r);
+        CHECK(maxdiff(vec(var.begin() + (size_t)r * p.M, var.begin() + (size_t)(r + 1) * p.M), ref.var) <= 1e-8, "tail-block var rank %d", r);
+      }
+    }
+  }
   opt("dist_group", 2);
   {
     // the automatic width schedule on block-cyclic models (512 / 256 / 128 by remaining size, thresholds scaled down):
