@@ -148,6 +148,8 @@ int gpk_set_option(const char* key, double value) {
   } else if (k == "dist_group") {
     if (v < 1 || v > 64) return gpk_set_err(-1, "dist_group must be in 1..64");
     G.dist_group = v;
+  } else if (k == "se_scalar") {
+    G.se_scalar = v ? 1 : 0;
   } else if (k == "dist_tail") {
     G.dist_tail = v ? 1 : 0;
   } else if (k == "dist_tail_chunk") {
@@ -217,6 +219,7 @@ double gpk_get_option(const char* key) {
   if (k == "dist_group") return G.dist_group;
   if (k == "dist_pipeline") return G.dist_pipeline;
   if (k == "dist_tail") return G.dist_tail;
+  if (k == "se_scalar") return G.se_scalar;
   if (k == "dist_tail_chunk") return G.dist_tail_chunk;
   if (k == "dist_tail_from") return g_dist_tail_from;
   if (k == "dist_tail_col") return g_dist_tail_col;
@@ -289,7 +292,9 @@ static int se_build_host(const double* Rh, int nr, const double* Ch, int nc, int
   GPK_TRY(sc.get(&dO, (size_t)nrp * ncp));
   GPK_HIP(hipMemcpyAsync(dR, Rh, (size_t)nr * d * 8, hipMemcpyHostToDevice, s));
   if (!same) GPK_HIP(hipMemcpyAsync(dC, Ch, (size_t)nc * d * 8, hipMemcpyHostToDevice, s));
-  GPK_TRY(launch_se_build(dR, nr, nrp, same ? dR : dC, nc, ncp, se, same, mode, dO, ncp, 0, s));
+  SEScalarForm form;  // the scalar-operand form where it applies, like the model paths (same bits either way)
+  if (mode == 0 && d <= 8 && G.se_scalar) GPK_TRY(sc.get(&form.scratch, se_scratch_doubles(nrp, ncp, d, !same)));
+  GPK_TRY(launch_se_build(dR, nr, nrp, same ? dR : dC, nc, ncp, se, same, mode, dO, ncp, 0, s, 0, nullptr, form));
   GPK_HIP(hipMemcpy2DAsync(out_h, (size_t)nc * 8, dO, (size_t)ncp * 8, (size_t)nc * 8, nr, hipMemcpyDeviceToHost, s));
   GPK_HIP(hipStreamSynchronize(s));
   return 0;

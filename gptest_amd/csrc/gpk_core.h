@@ -42,6 +42,7 @@ struct Runtime {
   int lookahead = 1;
   int dist_group = 2;   // panels (of the middle width) per ownership block of a block-cyclic (multi-GPU) model
   int dist_tail = 1;      // block-cyclic models: the last tail_rows columns as one tail block on one rank, factored there by the tile pipeline
+  int se_scalar = 1;      // K / Kxz builds of models with d <= 8 in the scalar-operand form (SEScalarForm; 0: the LDS form, same bits)
   int dist_tail_chunk = 8; // ... whose panels are broadcast this many at a time
   int dist_pipeline = 1;  // multi-rank process: keep the substitution stream next to the communication stream and pipeline y / this rank's
                           // shard of the prediction behind the per-panel "available" events (fit_group_impl); 0: three streams, prediction afterwards
@@ -197,6 +198,12 @@ struct gpk_model {
   double* Lo(int o) const { return dL + ooff[o]; }
   size_t L_elems = 0;
   double *dX = nullptr, *dy = nullptr, *dw = nullptr;
+  // scalar-operand form of the K builder (SEScalarForm): the scaled training points + norms (left there by the K build; every
+  // later Kxz build of this model reads them as its column points) and, grown on demand, the scaled test points of a Kxz build
+  double *dXs = nullptr, *dZs = nullptr;
+  size_t dXs_elems = 0, dZs_elems = 0;
+  SEScalarForm k_form(int rows_ready = 0) const;            // for a K build (rows = columns = the training points)
+  int kxz_form(int Mpad, SEScalarForm* out);                // for a Kxz build of Mpad test points (after the K build)
   double *dK = nullptr, *dKcopy = nullptr, *dL = nullptr, *dDinv = nullptr;
   double* dscal = nullptr;  // [0] sum log diag L  [1] w.w
   double* hpin = nullptr;   // pinned host staging of a fit's read-back: [sum log diag L, w.w, info, -, mean(M), var(M)]

@@ -221,6 +221,10 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
   int rc = 0;
   m->dX_elems = growable ? np * (size_t)d : (size_t)N * d;
   rc |= dev_alloc_t(&m->dX, m->dX_elems);
+  if (!growable && d <= 8) {  // (a growing model's point set changes under the scaled copy)
+    m->dXs_elems = se_scratch_doubles((int)np, 0, d, false);
+    rc |= dev_alloc_t(&m->dXs, m->dXs_elems);
+  }
   rc |= dev_alloc_t(&m->dy, np);
   rc |= dev_alloc_t(&m->dw, np);
   rc |= dev_alloc_t(&m->dK, np * (size_t)m->ldk);
@@ -257,6 +261,8 @@ void model_destroy(gpk_model* m) {
   dev_free(m->dK, np * (size_t)m->ldk * 8);
   dev_free(m->dw, np * 8);
   dev_free(m->dy, np * 8);
+  if (m->dZs) dev_free(m->dZs, m->dZs_elems * 8);
+  if (m->dXs) dev_free(m->dXs, m->dXs_elems * 8);
   dev_free(m->dX, m->dX_elems * 8);
   if (m->hpin) G.hpin_pool[m->hpin_doubles].push_back(m->hpin);
   for (size_t i = m->ev.size(); i-- > 0;) G.ev_dep_free.push_back(m->ev[i]);
@@ -1170,18 +1176,42 @@ int potrf_group(gpk_model* const* ms, int n) {
 }
 
 // K(X,X) into this rank's block columns (only tiles on/below the diagonal unless a full copy is kept)
+SEScalarForm gpk_model::k_form(int rows_ready) const {
+  SEScalarForm f;
+  if (dXs && G.se_scalar) { f.scratch = dXs; f.rows_ready = rows_ready; }
+  return f;
+}
+int gpk_model::kxz_form(int Mpad, SEScalarForm* out) {
+  *out = SEScalarForm();
+  if (!dXs || !G.se_scalar) return 0;
+  const size_t need = se_scratch_doubles(Mpad, 0, d, false);
+  if (dZs_elems < need) {  // (a buffer from the pool: the same test-set size gets the same pointer back)
+    if (dZs) dev_free(dZs, dZs_elems * 8);
+    dZs = nullptr;
+    dZs_elems = 0;
+    GPK_TRY(dev_alloc_t(&dZs, need));
+    dZs_elems = need;
+  }
+  out->scratch = dZs;
+  out->cols_scaled = dXs;
+  out->cols_pad = Npad;
+  return 0;
+}
 int build_K(gpk_model* m) {
   hipStream_t s = G.s_main;
   const int np_ = m->Npad;
   if (m->P == 1)
-    return launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s);
+    return launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s, 0, nullptr, m->k_form());
+  // the scaled training points once (also on a rank that owns no column: its Kxz builds read them), every block with rows_ready
+  const SEScalarForm kf = m->k_form(1);
+  if (kf.scratch) GPK_TRY(launch_se_scale(m->dX, m->N, np_, m->se, m->dX, kf.scratch, s));
   for (const gpk_model::ColRange& cr : m->owned_ranges()) {  // one launch per owned block (cyclic blocks, then the tail block on its owner)
     int nc = m->N - cr.gc0;
     if (nc > cr.ncols) nc = cr.ncols;
     if (nc < 0) nc = 0;
     // column points of this block (clamped pointer: nc == 0 blocks are pure padding)
     const double* Cc = m->dX + (size_t)(nc > 0 ? cr.gc0 : 0) * m->d;
-    GPK_TRY(launch_se_build(m->dX, m->N, np_, Cc, nc, cr.ncols, m->se, 1, 0, m->dK + cr.lc0, m->ldk, 1, s, cr.gc0, m->dX));
+    GPK_TRY(launch_se_build(m->dX, m->N, np_, Cc, nc, cr.ncols, m->se, 1, 0, m->dK + cr.lc0, m->ldk, 1, s, cr.gc0, m->dX, kf));
   }
   return 0;
 }
@@ -1287,7 +1317,11 @@ static int fit_group_impl(gpk_model* const* ms, int n, const GroupPredict* gp) {
       hipEvent_t* ev_avail = m->ev.data();
       GPK_HIP(hipStreamWaitEvent(sq, m->ev[2 * m->nP], 0));
       if (m->has_y) GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, sq));
-      if (cnt > 0) GPK_TRY(launch_se_build(gp->dZ + (size_t)m0 * m->d, cnt, mp, m->dX, m->N, np_, m->se, 0, 0, gp->bufs[i].dR, np_, 0, sq));
+      if (cnt > 0) {
+        SEScalarForm zf;
+        GPK_TRY(m->kxz_form(mp, &zf));
+        GPK_TRY(launch_se_build(gp->dZ + (size_t)m0 * m->d, cnt, mp, m->dX, m->N, np_, m->se, 0, 0, gp->bufs[i].dR, np_, 0, sq, 0, nullptr, zf));
+      }
       for (int p = 0; p < m->nP; ++p) {
         const int c0 = m->pc0[p], w = m->pw[p], h = np_ - c0;
         GPK_HIP(hipStreamWaitEvent(sq, ev_avail[p], 0));
@@ -1358,7 +1392,7 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp) {
     GPK_TRY(launch_stamp(G.dstamps + 447, s));  // "stamp_start": the fit begins (before the K build)
   }
   timer_begin("kbuild", s, (m->keep_k ? 8.0 : 4.0) * np_ * np_ + 8.0 * m->N * m->d);
-  GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s));
+  GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s, 0, nullptr, m->k_form()));
   timer_end("kbuild", s);
   if (m->keep_k)
     GPK_HIP(hipMemcpy2DAsync(m->dKcopy, (size_t)np_ * 8, m->dK, (size_t)m->ldk * 8, (size_t)np_ * 8, np_, hipMemcpyDeviceToDevice, s));
@@ -1405,7 +1439,9 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp) {
     if (m->has_y) GPK_HIP(hipMemcpyAsync(m->dw, m->dy, (size_t)np_ * 8, hipMemcpyDeviceToDevice, sy));
     if (fuse) {
       timer_begin("predict", sq);
-      GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq));
+      SEScalarForm zf;
+      GPK_TRY(m->kxz_form(fp->Mpad, &zf));
+      GPK_TRY(launch_se_build(fp->dZ, fp->M, fp->Mpad, m->dX, m->N, np_, m->se, 0, 0, fp->dR, np_, 0, sq, 0, nullptr, zf));
     }
   }
   const auto host_t0 = std::chrono::steady_clock::now();
@@ -1711,7 +1747,9 @@ int predict_device(gpk_model* m, const double* dZ, int M, int Mpad, double* dR, 
   hipStream_t sm = G.s_main;
   const int np_ = m->Npad;
   timer_begin("predict", sm);
-  GPK_TRY(launch_se_build(dZ, M, Mpad, m->dX, m->N, np_, m->se, 0, 0, dR, np_, 0, sm));
+  SEScalarForm zf;
+  GPK_TRY(m->kxz_form(Mpad, &zf));
+  GPK_TRY(launch_se_build(dZ, M, Mpad, m->dX, m->N, np_, m->se, 0, 0, dR, np_, 0, sm, 0, nullptr, zf));
   GPK_TRY(rows_forward_solve(m, Mpad, dR, dV));
   GPK_TRY(launch_row_stats(dV, np_, M, np_, m->dw, m->se.sf2, dmean, dvar, sm));
   timer_end("predict", sm);

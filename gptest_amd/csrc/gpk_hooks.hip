@@ -546,12 +546,21 @@ int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_o
   SEParams se{};
   se.d = d; se.sf2 = 1.0; se.diag_add = 0.01;
   for (int k = 0; k < d; ++k) se.ell[k] = 0.7;
-  int rc = launch_se_build(dX, N, np_, dX, N, np_, se, 1, mode, dK, np_, lower, s);
+  double* dS = nullptr;  // mode 3: the SE build in its scalar-operand form
+  const bool skip = mode == 4;  // ... without the pre-pass (timing only)
+  if (mode == 3 || mode == 4) {
+    GPK_TRY(dev_alloc_t(&dS, se_scratch_doubles(np_, np_, d, false)));
+    mode = 0;
+  }
+  SEScalarForm form;
+  form.scratch = dS;
+  int rc = launch_se_build(dX, N, np_, dX, N, np_, se, 1, mode, dK, np_, lower, s, 0, nullptr, form);
+  form.rows_ready = skip ? 1 : 0;
   hipEvent_t e0, e1;
   GPK_HIP(hipEventCreate(&e0));
   GPK_HIP(hipEventCreate(&e1));
   GPK_HIP(hipEventRecord(e0, s));
-  for (int r = 0; r < reps && !rc; ++r) rc = launch_se_build(dX, N, np_, dX, N, np_, se, 1, mode, dK, np_, lower, s);
+  for (int r = 0; r < reps && !rc; ++r) rc = launch_se_build(dX, N, np_, dX, N, np_, se, 1, mode, dK, np_, lower, s, 0, nullptr, form);
   GPK_HIP(hipEventRecord(e1, s));
   GPK_HIP(hipEventSynchronize(e1));
   float ms = 0;
@@ -561,6 +570,7 @@ int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_o
   (void)hipEventDestroy(e1);
   dev_free(dX, (size_t)N * d * 8);
   dev_free(dK, (size_t)np_ * np_ * 8);
+  if (dS) dev_free(dS, se_scratch_doubles(np_, np_, d, false) * 8);
   return rc;
 }
 

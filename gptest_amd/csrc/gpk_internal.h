@@ -124,9 +124,23 @@ struct SEParams {
 // out[r][c] (ld) for r < nr_pad, c < nc_pad; R (nr x d), Cc (nc x d) device row-major.
 // mode 0: sf2*exp(-0.5*r2) (+diag_add where global r == c if same_set); padded entries: identity if same_set else 0
 // mode 1: plain squared distance r2 (scaled by inv_ell, pass ones for raw)
+// The scalar-operand form of the builder (mode 0, d <= 8; k_build.hip): a pre-pass stores the centred, scaled points and their
+// norms, the tile kernel takes the row point of an output row as SGPR operands from scalar loads (no LDS, no barrier) and its
+// two column points ready-scaled from global memory.  The same bits as the LDS form.  Zero-initialised = the LDS form.
+struct SEScalarForm {
+  double* scratch = nullptr;           // se_scratch_doubles(...) doubles, the call's until the stream has passed the build
+  int rows_ready = 0;                  // an earlier call on this stream with the same R, nr_pad, p and centre has left the scaled rows there
+  const double* cols_scaled = nullptr; // column points scaled by an earlier call (the rows part of ITS scratch, same p and centre) ...
+  int cols_pad = 0;                    // ... of that many points (norms behind the points)
+};
+inline size_t se_scratch_doubles(int nr_pad, int nc_pad, int d, bool cols_need_scaling) {
+  return (size_t)nr_pad * (d + 1) + (cols_need_scaling ? (size_t)nc_pad * (d + 1) : 0);
+}
+// the pre-pass alone: S = the n_pad x d scaled points (zero rows beyond n), then their n_pad norms (d <= 8)
+int launch_se_scale(const double* P, int n, int n_pad, const SEParams& p, const double* centre, double* S, hipStream_t s);
 int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p,
                     int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0 = 0,
-                    const double* centre = nullptr);
+                    const double* centre = nullptr, const SEScalarForm& form = SEScalarForm());
 // centre (d doubles on the device): the point both sets are centred on in the dot-product form (d <= 8); nullptr = the
 // call's first column point.  Builds of one model in several calls pass the same centre (the same bits in every tile).
 

@@ -168,6 +168,88 @@ __global__ __launch_bounds__(256) void se_build_kernel(const double* __restrict_
   }
 }
 
+// ---- scalar-operand form (round 4).  The row point of an output row is the same for all 64 lanes of the wave that writes the
+// row segment: it belongs in SGPRs, not in LDS.  A pre-pass stores the centred, scaled row points and their squared norms
+// once (se_scale_rows_kernel: N x D + N doubles, 1 MiB at N = 16384); the tile kernel then fetches a row with ONE s_load_dwordx16
+// and feeds it to v_fma_f64 as the scalar operand: no LDS, no barrier, no broadcast reads (the LDS form spends four
+// ds_read_b128 + one ds_read_b64 per 128 output elements, and d = 8 costs 0.033 ms more than d = 4 for exactly that reason:
+// profiles/r04_kbuild_bench.txt).  Same operations in the same order as se_build_kernel<D, 0>: the same bits (tests).
+template <int D>
+__global__ __launch_bounds__(256) void se_scale_rows_kernel(const double* __restrict__ R, int nr, int nr_pad, SEParams p,
+                                                            const double* __restrict__ centre, double* __restrict__ Rs,
+                                                            double* __restrict__ Rn) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nr_pad) return;
+  const double pre = 0.8493218002880191;  // sqrt(log2(e) / 2)
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double v = (i < nr) ? (R[(long)i * D + k] - centre[k]) / p.ell[k] * pre : 0.0;
+    Rs[(long)i * D + k] = v;
+    acc = fma(v, v, acc);
+  }
+  Rn[i] = acc;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void se_build_srow_kernel(const double* __restrict__ Rs, const double* __restrict__ Rn, int nr,
+                                                            const double* __restrict__ Cs, const double* __restrict__ Cn, int nc,
+                                                            SEParams p, int same_set, int lower_only, double* __restrict__ out,
+                                                            long ld, int col_g0) {
+  int tc = blockIdx.x, tr = blockIdx.y;
+  if (lower_only == 2) {
+    const int id = blockIdx.x;
+    int t = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+    while (t * (t + 1) / 2 > id) --t;
+    while ((t + 1) * (t + 2) / 2 <= id) ++t;
+    tr = t;
+    tc = id - t * (t + 1) / 2;
+  }
+  if (lower_only == 1 && col_g0 + tc * 128 > tr * 128 + 127) return;
+  const int r0 = tr * 128, c0 = tc * 128;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (one-wave workgroups, four per tile, measured the same)
+  const double lsf = log2(p.sf2);
+  const int ca = c0 + 2 * lane, cb = ca + 1;
+  double za[D], zb[D];  // this lane's two column points (scaled by the pre-pass: zero rows beyond nc) and their norms
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    za[k] = Cs[(long)ca * D + k];
+    zb[k] = Cs[(long)cb * D + k];
+  }
+  const double na = Cn[ca], nb = Cn[cb];
+  const bool edge = (r0 + 128 > nr) || (c0 + 128 > nc);
+  const bool diag = same_set && (col_g0 + c0 < r0 + 128) && (r0 < col_g0 + c0 + 128);
+  const double* __restrict__ rp = Rs + (long)(r0 + w * 32) * D;  // wave-uniform: scalar loads
+  const double* __restrict__ np = Rn + (r0 + w * 32);
+#pragma unroll 4
+  for (int rr = 0; rr < 32; ++rr) {
+    const int gi = r0 + w * 32 + rr;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double x = rp[rr * D + k];
+      s0 = fma(x, za[k], s0);
+      s1 = fma(x, zb[k], s1);
+    }
+    const double r = np[rr];
+    s0 = fma(-2.0, s0, r + na);
+    s1 = fma(-2.0, s1, r + nb);
+    double v0 = exp2_neg(lsf - s0), v1 = exp2_neg(lsf - s1);
+    if (diag) {
+      if (gi == col_g0 + ca) v0 += p.diag_add;
+      if (gi == col_g0 + cb) v1 += p.diag_add;
+    }
+    if (edge) {
+      const bool rok = gi < nr;
+      if (!(rok && ca < nc)) v0 = (same_set && gi == col_g0 + ca) ? 1.0 : 0.0;
+      if (!(rok && cb < nc)) v1 = (same_set && gi == col_g0 + cb) ? 1.0 : 0.0;
+    }
+    d2 o = {v0, v1};
+    __builtin_nontemporal_store(o, reinterpret_cast<d2*>(out + (long)gi * ld + ca));
+  }
+}
+
 template <int MODE>
 static void se_build_dispatch(int dd, dim3 grid, dim3 block, hipStream_t s, const double* R, int nr, const double* Cc, int nc,
                               const SEParams& p, int same_set, int lo, double* out, long ld, int col_g0,
@@ -191,8 +273,47 @@ static void se_build_dispatch(int dd, dim3 grid, dim3 block, hipStream_t s, cons
 #undef GPK_SE_CASE
 }
 
+template <int D>
+static void se_build_srow_launch(dim3 grid, hipStream_t s, const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad,
+                                 const SEParams& p, int same_set, int lo, double* out, long ld, int col_g0, const double* centre,
+                                 const SEScalarForm& f) {
+  double* Rs = f.scratch;
+  double* Rn = f.scratch + (size_t)nr_pad * D;
+  const double *Cs, *Cn;
+  if (!f.rows_ready) hipLaunchKernelGGL((se_scale_rows_kernel<D>), dim3((nr_pad + 255) / 256), dim3(256), 0, s, R, nr, nr_pad, p, centre, Rs, Rn);
+  // the column points: an aligned block of the row points (K, the block columns of a block-cyclic K), a set an earlier build has
+  // scaled (Kxz after K: the training points), or scaled here behind the rows
+  const bool cols_in_rows = Cc >= R && Cc + (size_t)nc * D <= R + (size_t)nr * D && (Cc - R) % D == 0 && (Cc - R) / D + nc_pad <= nr_pad;
+  if (cols_in_rows) {
+    Cs = Rs + (Cc - R);
+    Cn = Rn + (Cc - R) / D;
+  } else if (f.cols_scaled) {
+    Cs = f.cols_scaled;
+    Cn = f.cols_scaled + (size_t)f.cols_pad * D;
+  } else {
+    double* cs = f.scratch + (size_t)nr_pad * (D + 1);
+    hipLaunchKernelGGL((se_scale_rows_kernel<D>), dim3((nc_pad + 255) / 256), dim3(256), 0, s, Cc, nc, nc_pad, p, centre, cs, cs + (size_t)nc_pad * D);
+    Cs = cs;
+    Cn = cs + (size_t)nc_pad * D;
+  }
+  hipLaunchKernelGGL((se_build_srow_kernel<D>), grid, dim3(256), 0, s, Rs, Rn, nr, Cs, Cn, nc, p, same_set, lo, out, ld, col_g0);
+}
+
+int launch_se_scale(const double* P, int n, int n_pad, const SEParams& p, const double* centre, double* S, hipStream_t s) {
+  if (p.d < 1 || p.d > 8 || !S) return gpk_set_err(-1, "se_scale: d=%d outside 1..8 or no scratch", p.d);
+  const dim3 grid((n_pad + 255) / 256), block(256);
+  switch (p.d) {
+#define GPK_SCALE_CASE(DD) case DD: hipLaunchKernelGGL((se_scale_rows_kernel<DD>), grid, block, 0, s, P, n, n_pad, p, centre, S, S + (size_t)n_pad * DD); break;
+    GPK_SCALE_CASE(1) GPK_SCALE_CASE(2) GPK_SCALE_CASE(3) GPK_SCALE_CASE(4) GPK_SCALE_CASE(5) GPK_SCALE_CASE(6) GPK_SCALE_CASE(7) GPK_SCALE_CASE(8)
+#undef GPK_SCALE_CASE
+  }
+  GPK_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p,
-                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0, const double* centre) {
+                    int same_set, int mode, double* out, long ld, long lower_only, hipStream_t s, int col_g0, const double* centre,
+                    const SEScalarForm& form) {
   if (!centre) centre = Cc;  // the call's first column point
   if (nr_pad % 128 || nc_pad % 128 || (ld & 1) || ((uintptr_t)out & 15))
     return gpk_set_err(-1, "se_build: padded shape %dx%d ld %ld must be tile aligned", nr_pad, nc_pad, ld);
@@ -203,6 +324,16 @@ int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int n
     const unsigned nt = nr_pad / 128;
     grid = dim3(nt * (nt + 1) / 2, 1);
     lo = 2;
+  }
+  if (mode == 0 && form.scratch && p.d <= 8) {  // scalar-operand form
+    if (form.cols_scaled && form.cols_pad < nc_pad) return gpk_set_err(-1, "se_build: %d scaled column points, %d needed", form.cols_pad, nc_pad);
+    switch (p.d) {
+#define GPK_SROW_CASE(DD) case DD: se_build_srow_launch<DD>(grid, s, R, nr, nr_pad, Cc, nc, nc_pad, p, same_set, lo, out, ld, col_g0, centre, form); break;
+      GPK_SROW_CASE(1) GPK_SROW_CASE(2) GPK_SROW_CASE(3) GPK_SROW_CASE(4) GPK_SROW_CASE(5) GPK_SROW_CASE(6) GPK_SROW_CASE(7) GPK_SROW_CASE(8)
+#undef GPK_SROW_CASE
+    }
+    GPK_HIP(hipGetLastError());
+    return 0;
   }
   if (mode == 0) se_build_dispatch<0>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0, centre);
   else if (mode == 1) se_build_dispatch<1>(p.d, grid, block, s, R, nr, Cc, nc, p, same_set, lo, out, ld, col_g0, centre);

@@ -7,9 +7,10 @@ _lib.init()
 l = _lib.lib()
 ms = ctypes.c_double()
 N = 16384
-for d in (8, 4):
+for rep in range(3):
+  for d in (8, 4):
     for lower in (1, 0):
-        for mode, nm in ((0, "SE"), (1, "sqdist"), (2, "stores only")):
-            hooks().gpk_bench_se_build(N, d, mode, lower, 10, ctypes.byref(ms))
+      for mode, nm in ((0, "SE"), (3, "SE scalar"), (4, "SE scalar, no pre-pass"), (1, "sqdist"), (2, "stores only")):
+            hooks().gpk_bench_se_build(N, d, mode, lower, 50, ctypes.byref(ms))
             byts = (4.0 if lower else 8.0) * N * N
-            print("kbuild N=%d d=%d %-5s %-11s: %.3f ms  %.2f TB/s written" % (N, d, "lower" if lower else "full", nm, ms.value, byts / ms.value / 1e9))
+            print("kbuild N=%d d=%d %-5s %-22s: %.3f ms  %.2f TB/s written" % (N, d, "lower" if lower else "full", nm, ms.value, byts / ms.value / 1e9))

@@ -34,6 +34,7 @@ while not math.isnan(_lib.get_option("stamp_corner_%d" % len(cr))):
     cr.append(_lib.get_option("stamp_corner_%d" % len(cr)))
 if cr:
     print("lazy corner from column %d: catch-up launches done at (ms): %s" % (_lib.get_option("potrf_corner_from"), " ".join("%.2f" % x for x in cr)))
+print("posterior start (K build queued) %.3f ms before panel 0 was factored" % -_lib.get_option("stamp_start"))
 print("chain at (ms): %s" % " ".join("%.2f" % x for x in ch))
 sb = [b for _, _, b in rows]
 print("substitution lag behind the chain (us): %s" % " ".join("%.0f" % (1e3 * (b - a)) for _, a, b in rows))

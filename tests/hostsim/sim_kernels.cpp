@@ -6,6 +6,7 @@
 #include "gpk_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 thread_local dim3 blockIdx, threadIdx, blockDim, gridDim;
 int g_gemm_polite = 1;
@@ -156,10 +157,54 @@ int launch_potf2_chain(double* A, long lda, double* L, long ldl, double* Dinv, i
 int launch_flag_set(unsigned* flag, unsigned v, hipStream_t) { *flag = v; return 0; }
 int launch_flag_probe(const unsigned* flag, unsigned want, unsigned* seen, hipStream_t) { (void)flag; (void)want; *seen = 1; return 0; }  // (the host simulation runs every stream in enqueue order)
 
+// the scalar-operand form's contract (SEScalarForm): what the pre-pass would leave in the scratch -- scaled points, then norms
+static void sim_scale(const double* P, int n, int n_pad, const SEParams& p, const double* centre, std::vector<double>* S) {
+  S->assign((size_t)n_pad * (p.d + 1), 0.0);
+  for (int i = 0; i < n; ++i) {
+    double acc = 0.0;
+    for (int k = 0; k < p.d; ++k) {
+      const double v = (P[(long)i * p.d + k] - centre[k]) / p.ell[k] * 0.8493218002880191;
+      (*S)[(size_t)i * p.d + k] = v;
+      acc = std::fma(v, v, acc);
+    }
+    (*S)[(size_t)n_pad * p.d + i] = acc;
+  }
+}
+int launch_se_scale(const double* P, int n, int n_pad, const SEParams& p, const double* centre, double* S, hipStream_t) {
+  if (p.d < 1 || p.d > 8 || !S) return gpk_set_err(-1, "se_scale: d=%d outside 1..8 or no scratch", p.d);
+  std::vector<double> v;
+  sim_scale(P, n, n_pad, p, centre, &v);
+  std::memcpy(S, v.data(), v.size() * 8);
+  return 0;
+}
 int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int nc, int nc_pad, const SEParams& p, int same_set,
-                    int mode, double* out, long ld, long lower_only, hipStream_t, int col_g0, const double*) {
+                    int mode, double* out, long ld, long lower_only, hipStream_t, int col_g0, const double* centre, const SEScalarForm& form) {
   if (nr_pad % 128 || nc_pad % 128 || (ld & 1)) return gpk_set_err(-1, "se_build: padded shape must be tile aligned");
   if (p.d < 1 || p.d > 32) return gpk_set_err(-1, "se_build: input dimension d=%d outside 1..32", p.d);
+  if (!centre) centre = Cc;
+  if (mode == 0 && form.scratch && p.d <= 8) {
+    // touch exactly what the device path touches (AddressSanitizer sees the extents) and hold the caller to the contract:
+    // "rows_ready" / "cols_scaled" must really hold this call's scaled points (same p, same centre)
+    std::vector<double> S;
+    sim_scale(R, nr, nr_pad, p, centre, &S);
+    if (form.rows_ready) {
+      if (std::memcmp(form.scratch, S.data(), S.size() * 8)) return gpk_set_err(-1, "se_build (sim): rows_ready, but the scratch does not hold this call's scaled rows");
+    } else {
+      std::memcpy(form.scratch, S.data(), S.size() * 8);
+    }
+    const bool cols_in_rows = Cc >= R && Cc + (size_t)nc * p.d <= R + (size_t)nr * p.d && (Cc - R) % p.d == 0 && (Cc - R) / p.d + nc_pad <= nr_pad;
+    if (!cols_in_rows) {
+      std::vector<double> C;
+      if (form.cols_scaled) {
+        if (form.cols_pad < nc_pad) return gpk_set_err(-1, "se_build: %d scaled column points, %d needed", form.cols_pad, nc_pad);
+        sim_scale(Cc, nc, form.cols_pad, p, centre, &C);
+        if (std::memcmp(form.cols_scaled, C.data(), C.size() * 8)) return gpk_set_err(-1, "se_build (sim): cols_scaled does not hold this call's scaled column points");
+      } else {
+        sim_scale(Cc, nc, nc_pad, p, centre, &C);
+        std::memcpy(form.scratch + (size_t)nr_pad * (p.d + 1), C.data(), C.size() * 8);
+      }
+    }
+  }
   for (int tr = 0; tr < nr_pad / 128; ++tr)
     for (int tc = 0; tc < nc_pad / 128; ++tc) {
       if (lower_only && col_g0 + tc * 128 > tr * 128 + 127) continue;
