@@ -148,6 +148,8 @@ int gpk_set_option(const char* key, double value) {
   } else if (k == "dist_group") {
     if (v < 1 || v > 64) return gpk_set_err(-1, "dist_group must be in 1..64");
     G.dist_group = v;
+  } else if (k == "kbuild_split") {
+    G.kbuild_split = v ? 1 : 0;
   } else if (k == "se_scalar") {
     G.se_scalar = v ? 1 : 0;
   } else if (k == "dist_tail") {
@@ -220,6 +222,8 @@ double gpk_get_option(const char* key) {
   if (k == "dist_pipeline") return G.dist_pipeline;
   if (k == "dist_tail") return G.dist_tail;
   if (k == "se_scalar") return G.se_scalar;
+  if (k == "kbuild_split") return G.kbuild_split;
+  if (k == "kbuild_split_used") return g_kbuild_split;
   if (k == "dist_tail_chunk") return G.dist_tail_chunk;
   if (k == "dist_tail_from") return g_dist_tail_from;
   if (k == "dist_tail_col") return g_dist_tail_col;

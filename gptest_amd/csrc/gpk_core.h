@@ -42,6 +42,7 @@ struct Runtime {
   int lookahead = 1;
   int dist_group = 2;   // panels (of the middle width) per ownership block of a block-cyclic (multi-GPU) model
   int dist_tail = 1;      // block-cyclic models: the last tail_rows columns as one tail block on one rank, factored there by the tile pipeline
+  int kbuild_split = 0;   // fused one-GPU fits: K's first block column as a launch of its own, so that panel 0 is factored beside the rest of the build (OFF: the build's waves fill every SIMD and panel 0 takes 0.58 instead of 0.41 ms beside it -- 20 us gained, none in the posterior)
   int se_scalar = 1;      // K / Kxz builds of models with d <= 8 in the scalar-operand form (SEScalarForm; 0: the LDS form, same bits)
   int dist_tail_chunk = 8; // ... whose panels are broadcast this many at a time
   int dist_pipeline = 1;  // multi-rank process: keep the substitution stream next to the communication stream and pipeline y / this rank's
@@ -200,6 +201,7 @@ struct gpk_model {
   double *dX = nullptr, *dy = nullptr, *dw = nullptr;
   // scalar-operand form of the K builder (SEScalarForm): the scaled training points + norms (left there by the K build; every
   // later Kxz build of this model reads them as its column points) and, grown on demand, the scaled test points of a Kxz build
+  hipEvent_t ev_kfirst = nullptr;  // (set by fit_enqueue around its potrf_device call) K's first block column is built; the rest follows on s_main
   double *dXs = nullptr, *dZs = nullptr;
   size_t dXs_elems = 0, dZs_elems = 0;
   SEScalarForm k_form(int rows_ready = 0) const;            // for a K build (rows = columns = the training points)
@@ -257,6 +259,7 @@ int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* 
 // fit + sharded prediction in one go: the y and prediction substitutions pipelined behind the per-panel events of the block-cyclic factorisation
 int fit_predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var);
 extern int g_dist_tail_from;        // first panel the last block-cyclic factorisation ran through the tile pipeline on the tail's owner (-1: none)
+extern int g_kbuild_split;          // 1 if the last fused fit built K in two launches (first block column, rest)
 extern int g_dist_tail_col;         // ... and its first column
 extern int g_dist_pipelined;        // 1 if the last block-cyclic fit queued its substitutions behind the panel events
 int build_K(gpk_model* m);                                      // dX -> dK (local block columns)

@@ -843,10 +843,12 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
     }
     return 0;
   };
-  // s_panel must not start before the K build queued on s_main has finished
-  GPK_HIP(hipEventRecord(ev_start, sm));
-  GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
+  // s_panel must not start before the K build queued on s_main has finished -- or, where the caller built block column 0 first
+  // (gpk_model::ev_kfirst), before that: panel 0 only reads its own block column; everything after it waits for the whole build
   const int o_tail = tail_first_panel(m);  // outer panels from here on go through the tile pipeline
+  const bool early0 = m->ev_kfirst && o_tail > 0;
+  GPK_HIP(hipEventRecord(ev_start, sm));
+  GPK_HIP(hipStreamWaitEvent(sp, early0 ? m->ev_kfirst : ev_start, 0));
   g_potrf_tail_from = (o_tail < nO) ? m->ofirst[o_tail] : -1;
   if (o_tail == 0) return potrf_tail(m, 0, nullptr, after_panel);
   // Lazy corner (Runtime::corner_from): a panel in front of a boundary b updates columns < b only; the region behind the boundary
@@ -858,6 +860,7 @@ int potrf_device(gpk_model* m, const std::function<int(int)>* after_panel) {
   for (int i = 0; i < 3; ++i) g_potrf_corner[i] = (i < (int)regs.size()) ? regs[i].b : 0;
   if (!regs.empty()) GPK_TRY(corner_stream_ensure());
   GPK_TRY(factor_outer(0, sp, nullptr));
+  if (early0) GPK_HIP(hipStreamWaitEvent(sp, ev_start, 0));
   for (int o = 0; o < nO; ++o) {
     const int r0 = m->oc0[o] + m->ow[o];             // first row/col of the trailing matrix
     CornerRegion* bd = nullptr;                       // the region this panel's update brings up to date (it ends at that boundary)
@@ -1068,6 +1071,7 @@ static int bcast_tail_panels(gpk_model* m, int q0, int q1, hipStream_t s) {
 //      stream, then potrf_tail over the tail's panels, each of which is broadcast (communication stream) once all of its rows are in
 //      place.  Everybody else: receives the tail's panels in order.
 int g_dist_tail_from = -1, g_dist_tail_col = -1;
+int g_kbuild_split = 0;
 static int dist_tail_phase(gpk_model* m) {
   hipStream_t sm = G.s_main, sp = G.s_panel, sc = comm_stream();
   const int nP = m->nP, pt = m->p_tail, p = pt - 1, np_ = m->Npad;
@@ -1392,7 +1396,29 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp) {
     GPK_TRY(launch_stamp(G.dstamps + 447, s));  // "stamp_start": the fit begins (before the K build)
   }
   timer_begin("kbuild", s, (m->keep_k ? 8.0 : 4.0) * np_ * np_ + 8.0 * m->N * m->d);
-  GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s, 0, nullptr, m->k_form()));
+  // K in two launches where the look-ahead schedule follows (option kbuild_split, off: measured, no gain): block column 0 over
+  // all rows, then the lower triangle behind it -- the chain stream factors panel 0 (0.4 ms of leaves and skinny GEMMs at
+  // N = 16384) beside the second launch instead of behind it.  The same tiles from the same kernels: the same bits.
+  const int w0 = m->ow[0];
+  const bool split = G.kbuild_split && !m->keep_k && !m->k_only && m->P == 1 && G.lookahead && m->nP >= 3 && tail_first_panel(m) > 0 &&
+                     np_ >= 4 * w0 && m->N > w0;
+  g_kbuild_split = split ? 1 : 0;
+  m->ev_kfirst = nullptr;
+  if (split) {
+    GPK_TRY(model_events(m, 3 * m->nP + 6));
+    GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, w0, w0, m->se, 1, 0, m->dK, m->ldk, 1, s, 0, m->dX, m->k_form()));
+    m->ev_kfirst = m->ev[2 * m->nP + 5];
+    GPK_HIP(hipEventRecord(m->ev_kfirst, s));
+    SEScalarForm fb = m->k_form(1);  // rows w0.. of the scaled set the first launch has left
+    if (fb.scratch) {
+      fb.scratch += (size_t)w0 * m->d;
+      fb.rows_norms = m->dXs + (size_t)np_ * m->d + w0;
+    }
+    const double* Xb = m->dX + (size_t)w0 * m->d;
+    GPK_TRY(launch_se_build(Xb, m->N - w0, np_ - w0, Xb, m->N - w0, np_ - w0, m->se, 1, 0, m->dK + (size_t)w0 * m->ldk + w0, m->ldk, 1, s, 0, m->dX, fb));
+  } else {
+    GPK_TRY(launch_se_build(m->dX, m->N, np_, m->dX, m->N, np_, m->se, 1, 0, m->dK, m->ldk, m->keep_k ? 0 : 1, s, 0, nullptr, m->k_form()));
+  }
   timer_end("kbuild", s);
   if (m->keep_k)
     GPK_HIP(hipMemcpy2DAsync(m->dKcopy, (size_t)np_ * 8, m->dK, (size_t)m->ldk * 8, (size_t)np_ * 8, np_, hipMemcpyDeviceToDevice, s));
@@ -1445,7 +1471,9 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp) {
     }
   }
   const auto host_t0 = std::chrono::steady_clock::now();
-  GPK_TRY(potrf_device(m));
+  const int prc = potrf_device(m);
+  m->ev_kfirst = nullptr;
+  GPK_TRY(prc);
   G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   timer_end("potrf", s);
   // s_main has joined the last panel: the log-determinant can run while the substitution stream finishes

@@ -130,6 +130,7 @@ struct SEParams {
 struct SEScalarForm {
   double* scratch = nullptr;           // se_scratch_doubles(...) doubles, the call's until the stream has passed the build
   int rows_ready = 0;                  // an earlier call on this stream with the same R, nr_pad, p and centre has left the scaled rows there
+  const double* rows_norms = nullptr;  // (with rows_ready) the rows are a sub-range of a larger scaled set: scratch = its first row, the norms here
   const double* cols_scaled = nullptr; // column points scaled by an earlier call (the rows part of ITS scratch, same p and centre) ...
   int cols_pad = 0;                    // ... of that many points (norms behind the points)
 };

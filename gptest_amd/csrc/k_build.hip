@@ -278,9 +278,9 @@ static void se_build_srow_launch(dim3 grid, hipStream_t s, const double* R, int 
                                  const SEParams& p, int same_set, int lo, double* out, long ld, int col_g0, const double* centre,
                                  const SEScalarForm& f) {
   double* Rs = f.scratch;
-  double* Rn = f.scratch + (size_t)nr_pad * D;
+  const double* Rn = (f.rows_ready && f.rows_norms) ? f.rows_norms : f.scratch + (size_t)nr_pad * D;
   const double *Cs, *Cn;
-  if (!f.rows_ready) hipLaunchKernelGGL((se_scale_rows_kernel<D>), dim3((nr_pad + 255) / 256), dim3(256), 0, s, R, nr, nr_pad, p, centre, Rs, Rn);
+  if (!f.rows_ready) hipLaunchKernelGGL((se_scale_rows_kernel<D>), dim3((nr_pad + 255) / 256), dim3(256), 0, s, R, nr, nr_pad, p, centre, Rs, Rs + (size_t)nr_pad * D);
   // the column points: an aligned block of the row points (K, the block columns of a block-cyclic K), a set an earlier build has
   // scaled (Kxz after K: the training points), or scaled here behind the rows
   const bool cols_in_rows = Cc >= R && Cc + (size_t)nc * D <= R + (size_t)nr * D && (Cc - R) % D == 0 && (Cc - R) / D + nc_pad <= nr_pad;

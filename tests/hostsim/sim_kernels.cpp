@@ -188,7 +188,9 @@ int launch_se_build(const double* R, int nr, int nr_pad, const double* Cc, int n
     std::vector<double> S;
     sim_scale(R, nr, nr_pad, p, centre, &S);
     if (form.rows_ready) {
-      if (std::memcmp(form.scratch, S.data(), S.size() * 8)) return gpk_set_err(-1, "se_build (sim): rows_ready, but the scratch does not hold this call's scaled rows");
+      const double* norms = form.rows_norms ? form.rows_norms : form.scratch + (size_t)nr_pad * p.d;
+      if (std::memcmp(form.scratch, S.data(), (size_t)nr_pad * p.d * 8) || std::memcmp(norms, S.data() + (size_t)nr_pad * p.d, (size_t)nr_pad * 8))
+        return gpk_set_err(-1, "se_build (sim): rows_ready, but the scratch does not hold this call's scaled rows");
     } else {
       std::memcpy(form.scratch, S.data(), S.size() * 8);
     }

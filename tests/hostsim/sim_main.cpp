@@ -144,6 +144,21 @@ int main() {
     opt("nb_big_until", 8192); opt("nb_small_from", 2048); opt("tail_rows", 0); opt("pair_update", 1);
   }
 
+  {
+    // K in two launches (block column 0, then the triangle behind it: rows_ready / rows_norms of the scalar-operand form), panel 0
+    // factored behind the first one
+    opt("nb", 128); opt("tail_rows", 512); opt("kbuild_split", 1);
+    check_fit_predict(make_problem(1300, 3, 30), "posterior with the two-launch K build");
+    CHECK(gpk_get_option("kbuild_split_used") == 1, "two-launch K build used");
+    opt("se_scalar", 0);
+    check_fit_predict(make_problem(1300, 3, 30), "posterior with the two-launch K build, LDS form");
+    CHECK(gpk_get_option("kbuild_split_used") == 1, "two-launch K build used (LDS form)");
+    opt("kbuild_split", 0);
+    check_fit_predict(make_problem(1300, 3, 30), "posterior with the one-launch K build, LDS form");
+    CHECK(gpk_get_option("kbuild_split_used") == 0, "two-launch K build off");
+    opt("se_scalar", 1); opt("nb", 0); opt("tail_rows", 0);
+  }
+
   // ---- block-cyclic schedule on virtual ranks (look-ahead and plain), against the one-rank factor
   for (int la : {1, 0}) for (int grp : {1, 2, 3}) {
     opt("lookahead", la);

@@ -1120,6 +1120,36 @@ def test_block_cyclic_fit_emulated_ranks(gpk, N, d, P):
     np.testing.assert_allclose(LP, Lr, rtol=1e-9, atol=1e-10)
 
 
+@pytest.mark.parametrize("N,d,M", [(6000, 8, 300), (9000, 3, 1024), (5200, 4, 129)])
+def test_two_launch_k_build_is_bitwise_the_single_launch(gpk, N, d, M):
+    """Round 4: a fused one-GPU fit can build K as block column 0 (all rows) and then the lower triangle behind it (option
+    kbuild_split; off, it gains nothing: the build starves panel 0), with the chain stream factoring panel 0 behind the first
+    launch instead of behind the whole build.  The same tiles from the same kernel: the posterior is bit for bit the
+    single-launch one, with either form of the builder (the scalar form reads a sub-range of the scaled set there)."""
+    from oracle import gpr_oracle as orc
+
+    X, y, Z, lh = orc.synthetic_problem(N, d, M)
+    out = {}
+    for split, scalar in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        gpk.set_option("kbuild_split", split)
+        gpk.set_option("se_scalar", scalar)
+        ms, nl = ctypes.c_double(), ctypes.c_double()
+        mean, var = np.zeros(M), np.zeros(M)
+        rc = gpk.lib().gpk_bench_posterior(_ptr(X), _ptr(y), N, d, _ptr(np.ascontiguousarray(lh)), _ptr(Z), M, 0, 1,
+                                           ctypes.byref(ms), ctypes.byref(nl), _ptr(mean), _ptr(var))
+        assert rc == 0, gpk.last_error()
+        assert gpk.get_option("kbuild_split_used") == split
+        out[(split, scalar)] = (nl.value, mean, var)
+    ref = out[(0, 0)]
+    for key, (nl, mean, var) in out.items():
+        assert nl == ref[0], key
+        np.testing.assert_array_equal(mean, ref[1])
+        np.testing.assert_array_equal(var, ref[2])
+    nl_o, fz_o, cov_o = orc.posterior_efficient(lh, X, y, Z)
+    assert abs(ref[0] - nl_o) <= RTOL * abs(nl_o)
+    np.testing.assert_allclose(ref[1], fz_o, rtol=RTOL, atol=RTOL * np.abs(fz_o).max())
+
+
 # ----------------------------------------------------------------------------- more edge cases
 @pytest.mark.parametrize("N,M,d,offset", [(300, 70, 1, 0.0), (513, 129, 2, 0.0), (1000, 256, 3, 50.0), (777, 5, 4, 0.0), (640, 1, 5, 0.0),
                                           (1300, 300, 6, 1.0e4), (900, 128, 7, 0.0), (2100, 1024, 8, 0.0)])
