@@ -360,7 +360,7 @@ def main():
                          "phases": phases,
                          "launches": tr_n, "avg_launch_ms": tr_ms / tr_n if tr_n else None,
                          "alg_flops_per_step_in_timed_launches": flops},
-            "kbuild": {"kernel": "se_build_kernel", "bound": "hbm", "ms": kb_ms / kb_n if kb_n else None, "unit": "GB/s",
+            "kbuild": {"kernel": "se_scale_rows_kernel + se_build_srow_kernel (scalar-operand form, timed together)", "bound": "hbm", "ms": kb_ms / kb_n if kb_n else None, "unit": "GB/s",
                        "peak": PEAK_HBM_GBS, "achieved": kb_bytes / (kb_ms * 1e-3) / 1e9 if kb_ms else None,
                        "frac": kb_bytes / (kb_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if kb_ms else None,
                        "note": "only the lower-triangle tiles are written: 4*N^2 + 8*N*d algorithmic bytes per build"},

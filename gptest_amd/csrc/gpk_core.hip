@@ -1907,8 +1907,12 @@ static int group_predict_gather(gpk_model* const* ms, int n, GroupPredict* gp, d
       GPK_HIP(hipMemcpyAsync(gp->bufs[i].dall, m->shard_loc, slice * 8, hipMemcpyDeviceToDevice, s));
     } else if (m->virtual_rank) {
       if (!m->vgroup) return gpk_set_err(-1, "internal: virtual rank %d without a group", m->r);
-      for (int q = 0; q < P; ++q)
-        GPK_HIP(hipMemcpyAsync(gp->bufs[i].dall + slice * q, m->vgroup[q]->shard_loc, slice * 8, hipMemcpyDeviceToDevice, s));
+      for (int q = 0; q < P; ++q) {
+        if (m->vgroup[q]->shard_loc)
+          GPK_HIP(hipMemcpyAsync(gp->bufs[i].dall + slice * q, m->vgroup[q]->shard_loc, slice * 8, hipMemcpyDeviceToDevice, s));
+        else  // (a single rank replayed alone, gpk_bench_dist_rank_alone: the others hold no shard)
+          GPK_HIP(hipMemsetAsync(gp->bufs[i].dall + slice * q, 0, slice * 8, s));
+      }
     } else {
       GPK_TRY(comm_allgather(m->shard_loc, gp->bufs[i].dall, slice, s));
     }

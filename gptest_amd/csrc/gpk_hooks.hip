@@ -574,6 +574,57 @@ int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_o
   return rc;
 }
 
+// One rank of a P-rank block-cyclic posterior ALONE on the GPU: the whole virtual job runs once (so that every rank holds
+// every panel of the true factor), then rank r's share is replayed `reps` times by itself -- its K blocks, its updates, the
+// panels it owns (incl. the tile pipeline if it owns the tail block), its shard of the prediction behind the panel events;
+// panels of other owners arrive as device copies from their models (the broadcasts' stand-in), never late.  ms_out[r]: the
+// time rank r needs when it never waits for a peer -- a LOWER bound of the job's time on P GPUs (max over r), and what one
+// GPU can measure of it.  ms_out[P]: the one-GPU posterior of the same problem in the same process.
+int gpk_bench_dist_rank_alone(const double* X, const double* y, int N, int d, const double* log_hyp, const double* Z, int M, int P,
+                              int reps, double* ms_out) {
+  GPK_TRY(rt_require());
+  if (!X || !y || !log_hyp || !Z || !ms_out || N < 1 || M < 1 || P < 2 || P > 16 || reps < 1)
+    return gpk_set_err(-1, "gpk_bench_dist_rank_alone: bad arguments");
+  hipStream_t s = G.s_main;
+  VirtualJob job;
+  GPK_TRY(job.create(N, d, P));
+  double* dZ = nullptr;
+  GPK_TRY(dev_alloc_t(&dZ, (size_t)M * d));
+  std::vector<double> hm((size_t)P * M), hv((size_t)P * M);
+  auto body = [&]() -> int {
+    GPK_HIP(hipMemcpyAsync(dZ, Z, (size_t)M * d * 8, hipMemcpyHostToDevice, s));
+    for (gpk_model* m : job.ms) {
+      GPK_TRY(decode_hyp(log_hyp, d, 0.0, m));
+      m->has_y = true;
+      GPK_HIP(hipMemcpyAsync(m->dX, X, (size_t)N * d * 8, hipMemcpyHostToDevice, s));
+      GPK_HIP(hipMemsetAsync(m->dy, 0, (size_t)m->Npad * 8, s));
+      GPK_HIP(hipMemcpyAsync(m->dy, y, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    }
+    std::vector<double*> pm(P), pv(P);
+    for (int r = 0; r < P; ++r) { pm[r] = hm.data() + (size_t)r * M; pv[r] = hv.data() + (size_t)r * M; }
+    GPK_TRY(fit_predict_group(job.ms.data(), P, dZ, M, pm.data(), pv.data()));
+    const double nl0 = job.ms[0]->nlml;
+    for (int r = 0; r < P; ++r) {
+      gpk_model* one = job.ms[r];
+      double best = 1e300;
+      for (int k = 0; k < reps + 1; ++k) {  // (first replay: warm-up)
+        GPK_HIP(hipStreamSynchronize(s));
+        const auto t0 = std::chrono::steady_clock::now();
+        GPK_TRY(fit_predict_group(&one, 1, dZ, M, &pm[r], &pv[r]));  // (ends with the read-back of the gathered prediction: synchronous)
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (k > 0 && ms < best) best = ms;
+        if (one->nlml != nl0) return gpk_set_err(-1, "internal: rank %d replayed alone disagrees with the group (%.17g vs %.17g)", r, one->nlml, nl0);
+      }
+      ms_out[r] = best;
+    }
+    return 0;
+  };
+  int rc = body();
+  if (rc) (void)hipStreamSynchronize(s);
+  dev_free(dZ, (size_t)M * d * 8);
+  return rc;
+}
+
 int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double* ms_out) {
   GPK_TRY(rt_require());
   hipStream_t s = G.s_main;

@@ -49,6 +49,11 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
  * library's own update / chain / substitution streams), `reps` small spinning launches (wgs workgroups, us_each microseconds) on each,
  * queued round robin.  out_us[i] = time per launch on stream i, out_us[nstreams] = host wall time per round. */
 int gpk_bench_streams(int nstreams, int high_mask, int low_mask, int wgs, int us_each, int reps, int use_lib_streams, double* out_us);
+/* One rank of a P-rank block-cyclic posterior ALONE on the GPU (P virtual ranks in this process; the whole job runs once, then
+ * each rank's share is replayed by itself `reps` times, panels of other owners arriving as device copies, never late):
+ * ms_out[r] = the best time of rank r, r < P -- a lower bound of the P-GPU job's time, max over r. */
+int gpk_bench_dist_rank_alone(const double* X, const double* y, int N, int d, const double* log_hyp, const double* Z, int M, int P,
+                              int reps, double* ms_out);
 /* LDS banking probe for rocprofv3 --pmc (scripts/lds_bank_probe.sh): `reps` ds_read_b64 per lane in one of six address patterns. */
 int gpk_bench_lds_bank_probe(int pattern, int reps);
 /* leaf kernel timing; dbg_skip bit 0 = skip elimination, bit 1 = skip inverse (timing only), bit 8 = the full-tile form. */
