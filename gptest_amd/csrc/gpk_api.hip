@@ -154,6 +154,9 @@ int gpk_set_option(const char* key, double value) {
     G.se_scalar = v ? 1 : 0;
   } else if (k == "dist_tail") {
     G.dist_tail = v ? 1 : 0;
+  } else if (k == "dist_tail_alone") {
+    if (v < -1 || v > 1) return gpk_set_err(-1, "gpk_set_option: dist_tail_alone must be -1, 0 or 1");
+    G.dist_tail_alone = (int)v;
   } else if (k == "dist_tail_chunk") {
     if (v < 1 || v > 64) return gpk_set_err(-1, "gpk_set_option: dist_tail_chunk must be 1..64");
     G.dist_tail_chunk = (int)v;
@@ -225,6 +228,8 @@ double gpk_get_option(const char* key) {
   if (k == "kbuild_split") return G.kbuild_split;
   if (k == "kbuild_split_used") return g_kbuild_split;
   if (k == "dist_tail_chunk") return G.dist_tail_chunk;
+  if (k == "dist_tail_alone") return G.dist_tail_alone;
+  if (k == "dist_tail_owner") return g_dist_tail_owner;
   if (k == "dist_tail_from") return g_dist_tail_from;
   if (k == "dist_tail_col") return g_dist_tail_col;
   if (k == "tail_rows") return G.tail_rows;

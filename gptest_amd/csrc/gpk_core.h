@@ -44,6 +44,7 @@ struct Runtime {
   int dist_tail = 1;      // block-cyclic models: the last tail_rows columns as one tail block on one rank, factored there by the tile pipeline
   int kbuild_split = 0;   // fused one-GPU fits: K's first block column as a launch of its own, so that panel 0 is factored beside the rest of the build (OFF: the build's waves fill every SIMD and panel 0 takes 0.58 instead of 0.41 ms beside it -- 20 us gained, none in the posterior)
   int se_scalar = 1;      // K / Kxz builds of models with d <= 8 in the scalar-operand form (SEScalarForm; 0: the LDS form, same bits)
+  int dist_tail_alone = -1; // the tail's owner keeps out of the cyclic part (gpk_model::Pc): -1 where the work model says so, 0 never, 1 whenever P >= 3
   int dist_tail_chunk = 8; // ... whose panels are broadcast this many at a time
   int dist_pipeline = 1;  // multi-rank process: keep the substitution stream next to the communication stream and pipeline y / this rank's
                           // shard of the prediction behind the per-panel "available" events (fit_group_impl); 0: three streams, prediction afterwards
@@ -145,13 +146,17 @@ struct gpk_model {
   // broadcast; its panels are broadcast behind the chain).  Local layout of a rank: its nloc_c cyclic blocks of the columns
   // below ct side by side, then (on t_own only) the Npad - ct tail columns.
   int ct = 0, t_own = 0, nloc_c = 0, p_tail = 0;  // p_tail: the panel that starts at ct
+  // Pc: the ranks that share the cyclic part.  P, or -- where the tail block alone is at least a fair share of the work (model_create:
+  // P >= 3 at the default sizes) -- P - 1: the tail's owner is then rank P - 1 and keeps out of the cyclic part (its peers' map is
+  // the cyclic one over Pc ranks), instead of carrying ALL updates of the tail block on top of a full cyclic share.
+  int Pc = 1;
   int owner_of_col(long c) const {
     if (ct > 0 && c >= ct) return t_own;
-    return P > 1 ? (int)((c / OB) % P) : 0;
+    return P > 1 ? (int)((c / OB) % Pc) : 0;
   }
   long local_col(long c) const {  // c must be owned
     if (ct > 0 && c >= ct) return (long)nloc_c * OB + (c - ct);
-    return P > 1 ? (c / OB / P) * OB + c % OB : c;
+    return P > 1 ? (c / OB / Pc) * OB + c % OB : c;
   }
   long local_from(long c) const {  // first local column whose global column is >= c (ldk if none)
     if (P == 1 && ct == 0) return c;
@@ -159,10 +164,12 @@ struct gpk_model {
     if (ct > 0 && c >= ct) return r == t_own ? (long)nloc_c * OB + (c - ct) : ldk;
     const long nb_all = (ct > 0 ? ct : Npad) / OB;  // cyclic blocks
     const long b = c / OB;
-    if ((int)(b % P) == r) return (b / P) * OB + c % OB;
-    long nb_ = b + 1;
-    while (nb_ < nb_all && (int)(nb_ % P) != r) ++nb_;
-    if (nb_ < nb_all) return (nb_ / P) * OB;
+    if (r < Pc) {
+      if ((int)(b % Pc) == r) return (b / Pc) * OB + c % OB;
+      long nb_ = b + 1;
+      while (nb_ < nb_all && (int)(nb_ % Pc) != r) ++nb_;
+      if (nb_ < nb_all) return (nb_ / Pc) * OB;
+    }
     return (ct > 0 && r == t_own) ? (long)nloc_c * OB : ldk;  // no cyclic block left: the tail block (its owner) or nothing
   }
   // the global column ranges this rank stores, in local order: (first global column, columns, first local column)
@@ -172,8 +179,8 @@ struct gpk_model {
     if (P == 1 && ct == 0) { v.push_back({0, Npad, 0}); return v; }
     const int nb_all = (ct > 0 ? ct : Npad) / OB;
     int lb = 0;
-    for (int b = 0; b < nb_all; ++b)
-      if (b % P == r) { v.push_back({b * OB, OB, (long)lb * OB}); ++lb; }
+    for (int b = 0; b < nb_all && r < Pc; ++b)
+      if (b % Pc == r) { v.push_back({b * OB, OB, (long)lb * OB}); ++lb; }
     if (ct > 0 && r == t_own) v.push_back({ct, Npad - ct, (long)nloc_c * OB});
     return v;
   }
@@ -260,6 +267,7 @@ int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* 
 int fit_predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var);
 extern int g_dist_tail_from;        // first panel the last block-cyclic factorisation ran through the tile pipeline on the tail's owner (-1: none)
 extern int g_kbuild_split;          // 1 if the last fused fit built K in two launches (first block column, rest)
+extern int g_dist_tail_owner;       // ... its owner; P + owner if that rank keeps out of the cyclic part
 extern int g_dist_tail_col;         // ... and its first column
 extern int g_dist_pipelined;        // 1 if the last block-cyclic fit queued its substitutions behind the panel events
 int build_K(gpk_model* m);                                      // dX -> dK (local block columns)

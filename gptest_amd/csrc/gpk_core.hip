@@ -209,10 +209,22 @@ int model_create(gpk_model** out, int N, int d, bool keep_k, int P, int r, bool 
       break;
     }
   }
+  // Who owns the tail, and does it take part in the cyclic map?  Work model (flops of the factorisation): the tail block costs
+  // T^2 ct (every column in front of it updates its lower half) + T^3 / 3, the cyclic part the rest of Npad^3 / 3.  Owner inside
+  // the map: it carries tail + cyclic / P.  Owner outside (rank P - 1, the others cyclic over P - 1): max(tail, cyclic / (P - 1)).
+  m->Pc = P;
   m->t_own = m->ct > 0 ? (m->ct / m->OB) % P : 0;
+  if (m->ct > 0 && P >= 3 && G.dist_tail_alone != 0) {
+    const double T = m->Npad - m->ct, n3 = (double)m->Npad * m->Npad * m->Npad / 3.0;
+    const double tail = T * T * m->ct + T * T * T / 3.0, cyc = n3 - tail;
+    if (G.dist_tail_alone > 0 || std::max(tail, cyc / (P - 1)) < tail + cyc / P) {
+      m->Pc = P - 1;
+      m->t_own = P - 1;
+    }
+  }
   m->nloc = 0;
-  for (int b = 0; b < (m->ct > 0 ? m->ct : m->Npad) / m->OB; ++b)
-    if (b % P == r) m->nloc++;
+  for (int b = 0; b < (m->ct > 0 ? m->ct : m->Npad) / m->OB && r < m->Pc; ++b)
+    if (b % m->Pc == r) m->nloc++;
   m->nloc_c = m->nloc;
   m->ldk = (P > 1) ? (long)m->nloc * m->OB + ((m->ct > 0 && r == m->t_own) ? m->Npad - m->ct : 0) : (long)m->Npad;
   if (m->ldk < m->OB) m->ldk = m->OB;
@@ -405,7 +417,7 @@ int dist_update(gpk_model* m, int p, long gc_lo, long gc_hi, hipStream_t s) {
   g.B = g.A; g.ldb = g.lda;
   g.C = m->dK + (long)r0 * m->ldk + lc_lo; g.ldc = m->ldk;
   g.m = rows; g.n = (int)(lc_hi - lc_lo); g.k = w; g.sub = 1; g.lower = 1;
-  g.cyc_P = m->P; g.cyc_r = m->r; g.cyc_NB = m->OB; g.cyc_lg0 = (int)(lc_lo / m->OB); g.cyc_c0 = (int)(lc_lo % m->OB);
+  g.cyc_P = m->Pc; g.cyc_r = m->r; g.cyc_NB = m->OB; g.cyc_lg0 = (int)(lc_lo / m->OB); g.cyc_c0 = (int)(lc_lo % m->OB);
   g.row_g0 = r0; g.brow_g0 = r0;
   // a rank's share of an update is 1/P of the tiles: the same latency rule as panel_update (every kernel of
   // k_gemm.hip rounds identically, so the factor does not depend on the choice)
@@ -1070,7 +1082,7 @@ static int bcast_tail_panels(gpk_model* m, int q0, int q1, hipStream_t s) {
 //      last cyclic panel; its update touches tail columns only.  Owner: three tile columns on the chain stream, the rest on the update
 //      stream, then potrf_tail over the tail's panels, each of which is broadcast (communication stream) once all of its rows are in
 //      place.  Everybody else: receives the tail's panels in order.
-int g_dist_tail_from = -1, g_dist_tail_col = -1;
+int g_dist_tail_from = -1, g_dist_tail_col = -1, g_dist_tail_owner = -1;
 int g_kbuild_split = 0;
 static int dist_tail_phase(gpk_model* m) {
   hipStream_t sm = G.s_main, sp = G.s_panel, sc = comm_stream();
@@ -1144,7 +1156,7 @@ int potrf_group(gpk_model* const* ms, int n) {
   const int nP = ms[0]->nP, P = ms[0]->P;
   for (int i = 0; i < n; ++i) {
     const gpk_model* m = ms[i];
-    if (m->P != P || m->nP != nP || m->Npad != ms[0]->Npad || m->OB != ms[0]->OB || m->ct != ms[0]->ct)
+    if (m->P != P || m->nP != nP || m->Npad != ms[0]->Npad || m->OB != ms[0]->OB || m->ct != ms[0]->ct || m->Pc != ms[0]->Pc || m->t_own != ms[0]->t_own)
       return gpk_set_err(-1, "potrf_group: rank models disagree on the block-cyclic layout");
     if (n > 1 && (!m->virtual_rank || n != P || m->r != i || m->vgroup != ms))
       return gpk_set_err(-1, "potrf_group: a group of %d needs the %d virtual ranks in rank order", n, P);
@@ -1167,6 +1179,7 @@ int potrf_group(gpk_model* const* ms, int n) {
   const int p_tail = ms[0]->ct > 0 ? ms[0]->p_tail : nP;  // from here on: the tail block, one rank's tile pipeline
   g_dist_tail_from = p_tail < nP ? p_tail : -1;
   g_dist_tail_col = p_tail < nP ? ms[0]->ct : -1;
+  g_dist_tail_owner = p_tail < nP ? (ms[0]->Pc < P ? P + ms[0]->t_own : ms[0]->t_own) : -1;  // (P + rank: the owner keeps out of the cyclic part)
   for (int p = 0; p < nP; ++p) {
     if (p_tail < nP && p + 1 == p_tail) {
       GPK_TRY(from_owner(ms[0]->t_own, [&](gpk_model* m) { return dist_tail_phase(m); }));

@@ -24,18 +24,21 @@ def env_rank():
     return rank, local, world
 
 
-def block_cyclic_owner(block, world, tail_from=None):
+def block_cyclic_owner(block, world, tail_from=None, tail_alone=False):
     """Owner rank of ownership block ``block`` (1-D block-cyclic).  Blocks from ``tail_from`` on form the
-    tail block, which belongs as a whole to the rank that owns block ``tail_from`` (gpk_model::ct in
-    gptest_amd/csrc/gpk_core.h: the chain-bound last columns are factored by one rank's tile pipeline)."""
+    tail block, which belongs as a whole to one rank (gpk_model::ct in gptest_amd/csrc/gpk_core.h: the chain-bound last
+    columns are factored by one rank's tile pipeline): the cyclic owner of block ``tail_from``, or -- ``tail_alone``,
+    gpk_model::Pc -- the last rank, which then keeps out of the cyclic part (the others share it, cyclic over world - 1)."""
+    if tail_from is not None and tail_alone and world >= 3:
+        return world - 1 if block >= tail_from else block % (world - 1)
     if tail_from is not None and block >= tail_from:
         block = tail_from
     return block % world
 
 
-def local_blocks(rank, world, nblocks, tail_from=None):
+def local_blocks(rank, world, nblocks, tail_from=None, tail_alone=False):
     """Global block-column indices owned by ``rank``."""
-    return [b for b in range(nblocks) if block_cyclic_owner(b, world, tail_from) == rank]
+    return [b for b in range(nblocks) if block_cyclic_owner(b, world, tail_from, tail_alone) == rank]
 
 
 def torch_bootstrap(payload):

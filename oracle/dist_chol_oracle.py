@@ -5,7 +5,8 @@ CPU over gloo (tests/test_dist_gloo.py).  Each rank holds only its own block col
 panels it received, exactly like gptest_amd/csrc/gpk_core.hip: potrf_group; `group` consecutive panels form one
 ownership block (gpk_model::OB, option dist_group): panel g belongs to rank (g // group) % world.  With `tail_from`
 (a panel index on an ownership-block boundary) the panels from there on form the tail block of gpk_model::ct: one rank owns
-and factors all of them, the others receive them `tail_chunk` panels per broadcast (dist_tail_phase)."""
+and factors all of them, the others receive them `tail_chunk` panels per broadcast (dist_tail_phase); with `tail_alone` that rank
+is the last one and owns nothing else (gpk_model::Pc: the cyclic part is shared by the other world - 1 ranks)."""
 import numpy as np
 
 
@@ -18,13 +19,15 @@ def torch_bcast(arr, root):
     return t.numpy()
 
 
-def cholesky_block_cyclic(A, nb, rank, world, bcast, group=1, tail_from=None, tail_chunk=1):
+def cholesky_block_cyclic(A, nb, rank, world, bcast, group=1, tail_from=None, tail_chunk=1, tail_alone=False):
     N = A.shape[0]
     nP = (N + nb - 1) // nb
     if tail_from is not None:
         assert 0 < tail_from < nP and tail_from % group == 0
 
     def owner(g):
+        if tail_from is not None and tail_alone and world >= 3:
+            return world - 1 if g >= tail_from else (g // group) % (world - 1)
         if tail_from is not None and g >= tail_from:
             g = tail_from
         return (g // group) % world

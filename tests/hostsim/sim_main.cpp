@@ -179,6 +179,7 @@ int main() {
   // ---- the tail block: the last tail_rows columns live on one rank, which runs the tile pipeline over them and broadcasts its panels
   for (int grp : {1, 2, 3}) for (int fused : {0, 2}) {
     opt("dist_group", grp); opt("nb", 128); opt("tail_rows", 768); opt("chain_fused", fused); opt("dist_tail_chunk", fused ? 4 : 1);
+    opt("dist_tail_alone", fused ? 0 : -1);  // (-1: the work model decides whether the tail's owner keeps out of the cyclic part -- here it does from P = 3 on)
     const int N = 1700;
     vec A((size_t)N * N);
     for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) { const double v = (i == j ? N + 1.0 : 0.0) + std::cos(0.1 * (i - j)); A[(size_t)i * N + j] = A[(size_t)j * N + i] = v; }
@@ -188,19 +189,20 @@ int main() {
       opt("dist_tail", 1);
       CHECK(gpk_test_dist_potrf(A.data(), N, P, LP.data()) == 0, "tail block P=%d", P);
       CHECK(gpk_get_option("dist_tail_from") > 0, "tail block used P=%d group=%d: %g", P, grp, gpk_get_option("dist_tail_from"));
+      CHECK((gpk_get_option("dist_tail_owner") >= P) == (!fused && P >= 3), "tail owner outside the cyclic part P=%d fused=%d: %g", P, fused, gpk_get_option("dist_tail_owner"));
       CHECK(maxdiff(L1, LP) == 0.0, "tail block P=%d group=%d diff %g", P, grp, maxdiff(L1, LP));
       opt("dist_tail", 0);
       CHECK(gpk_test_dist_potrf(A.data(), N, P, L0.data()) == 0, "no tail block P=%d", P);
       CHECK(gpk_get_option("dist_tail_from") < 0, "tail block off P=%d", P);
       CHECK(maxdiff(L0, LP) == 0.0, "tail block on/off P=%d group=%d diff %g", P, grp, maxdiff(L0, LP));
     }
-    opt("dist_tail", 1); opt("chain_fused", 0); opt("dist_tail_chunk", 8);
+    opt("dist_tail", 1); opt("chain_fused", 0); opt("dist_tail_chunk", 8); opt("dist_tail_alone", -1);
   }
   {
     Problem p = make_problem(1500, 3, 70);
     const Posterior ref = dense_posterior(p, p.N);
     opt("dist_group", 1); opt("nb", 128); opt("tail_rows", 640);
-    for (int P : {2, 3}) {
+    for (int P : {2, 3, 5}) {
       vec nl(P), mean((size_t)P * p.M), var((size_t)P * p.M);
       CHECK(gpk_test_dist_posterior(p.X.data(), p.y.data(), p.N, p.d, p.lh.data(), p.Z.data(), p.M, P, nl.data(), mean.data(), var.data()) == 0, "tail-block posterior P=%d", P);
       CHECK(gpk_get_option("dist_tail_from") > 0, "tail block used in the posterior P=%d", P);

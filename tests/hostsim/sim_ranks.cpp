@@ -32,12 +32,14 @@ static int rank_main(int rank, int P, const unsigned char* uid, int out_fd) {
     CHECK(std::fabs(nl - ref.nlml) <= 1e-9 * std::fabs(ref.nlml), "%s nlml %.12g vs %.12g (rank %d of %d)", what, nl, ref.nlml, rank, P);
     CHECK(maxdiff(m, ref.mean) <= 1e-8 && maxdiff(v, ref.var) <= 1e-8, "%s mean/var %g %g (rank %d of %d)", what, maxdiff(m, ref.mean), maxdiff(v, ref.var), rank, P);
   };
-  for (int pass = 0; pass < 6; ++pass) {  // default schedule; no look-ahead; three panels per ownership block; panels of three widths; no tail block; tail panels broadcast one by one
+  for (int pass = 0; pass < 8; ++pass) {  // default schedule; no look-ahead; three panels per ownership block; panels of three widths; no tail block; tail panels broadcast one by one
     if (pass == 1) opt("lookahead", 0);
     if (pass == 2) { opt("lookahead", 1); opt("dist_group", 3); }
     if (pass == 3) { opt("dist_group", 2); opt("nb_big_until", 256); opt("nb_small_from", 256); }  // 512 / 256 / 128 / 128 at N = 900
     if (pass == 4) { opt("nb_big_until", 8192); opt("nb_small_from", 4096); opt("dist_tail", 0); }
     if (pass == 5) { opt("dist_tail", 1); opt("dist_tail_chunk", 1); }
+    if (pass == 6) { opt("dist_tail_chunk", 8); opt("dist_tail_alone", 1); }   // the tail's owner = the last rank, outside the cyclic part (P >= 3)
+    if (pass == 7) opt("dist_tail_alone", 0);
     gpk_model* h = nullptr;
     double nl = 0;
     vec mean(p.M), var(p.M);
@@ -47,6 +49,7 @@ static int rank_main(int rank, int P, const unsigned char* uid, int out_fd) {
     if (P > 1) CHECK(gpk_get_option("dist_lookahead_used") == (pass == 1 ? 0 : 1), "look-ahead branch (pass %d)", pass);
     // the last columns as one tail block on one rank (tile pipeline there, chunked broadcasts): 1024 padded rows in two ownership
     // blocks of 512 under the default schedule, the second one is the tail block
+    if (P > 1 && pass >= 6) CHECK((gpk_get_option("dist_tail_owner") >= P) == (pass == 6 && P >= 3), "tail owner (pass %d): %g", pass, gpk_get_option("dist_tail_owner"));
     if (P > 1 && (pass == 0 || pass >= 4)) CHECK((gpk_get_option("dist_tail_from") > 0) == (pass != 4), "tail block (pass %d): %g", pass, gpk_get_option("dist_tail_from"));
     if (pass >= 4) CHECK(nl == sh.nlml[0] && std::memcmp(mean.data(), sh.mean[0], sizeof sh.mean[0]) == 0 && std::memcmp(var.data(), sh.var[0], sizeof sh.var[0]) == 0, "tail block on/off, chunked or not: bit for bit (pass %d)", pass);
     if (pass == 0) {
@@ -61,7 +64,7 @@ static int rank_main(int rank, int P, const unsigned char* uid, int out_fd) {
     }
     gpk_free(h);
   }
-  opt("dist_tail_chunk", 8);
+  opt("dist_tail_chunk", 8); opt("dist_tail_alone", -1);
   {
     gpk_model* h = nullptr;
     double nl = 0;

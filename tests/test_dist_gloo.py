@@ -20,14 +20,21 @@ def test_block_cyclic_ownership():
             for tail_from in (None, 1, nblocks - 2):
                 if tail_from is not None and not 0 < tail_from < nblocks:
                     continue
-                seen = []
-                for r in range(world):
-                    mine = dist.local_blocks(r, world, nblocks, tail_from)
-                    assert all(dist.block_cyclic_owner(b, world, tail_from) == r for b in mine)
-                    seen += mine
-                assert sorted(seen) == list(range(nblocks))
-                if tail_from is not None:  # the tail block has one owner, the one block tail_from has in the cyclic layout
-                    assert {dist.block_cyclic_owner(b, world, tail_from) for b in range(tail_from, nblocks)} == {tail_from % world}
+                for alone in (False, True):
+                    seen = []
+                    for r in range(world):
+                        mine = dist.local_blocks(r, world, nblocks, tail_from, alone)
+                        assert all(dist.block_cyclic_owner(b, world, tail_from, alone) == r for b in mine)
+                        seen += mine
+                    assert sorted(seen) == list(range(nblocks))
+                    if tail_from is None:
+                        continue
+                    # the tail block has ONE owner: the cyclic owner of block tail_from, or (alone, 3 ranks or more) the last rank,
+                    # which then owns nothing in front of the tail
+                    want = world - 1 if (alone and world >= 3) else tail_from % world
+                    assert {dist.block_cyclic_owner(b, world, tail_from, alone) for b in range(tail_from, nblocks)} == {want}
+                    if alone and world >= 3:
+                        assert all(dist.block_cyclic_owner(b, world, tail_from, alone) == b % (world - 1) for b in range(tail_from))
 
 
 def test_env_rank_parsing(monkeypatch):
@@ -66,8 +73,10 @@ WORKER = textwrap.dedent(
         assert np.allclose(L, ref, rtol=1e-11, atol=1e-11), (group, np.abs(L - ref).max())
     # ... and with the last panels as one tail block on one rank, sent a chunk of panels per broadcast (gpk_model::ct, dist_tail_phase)
     for group, tail_from, chunk in ((1, 3, 1), (1, 4, 2), (2, 4, 8), (3, 3, 3)):
-        Lt = dco.cholesky_block_cyclic(A, nb, rank, world, dco.torch_bcast, group=group, tail_from=tail_from, tail_chunk=chunk)
-        assert np.allclose(Lt, ref, rtol=1e-11, atol=1e-11), (group, tail_from, np.abs(Lt - ref).max())
+        for alone in ((False, True) if world >= 3 else (False,)):   # (alone: the last rank owns the tail block and nothing else, gpk_model::Pc)
+            Lt = dco.cholesky_block_cyclic(A, nb, rank, world, dco.torch_bcast, group=group, tail_from=tail_from, tail_chunk=chunk,
+                                           tail_alone=alone)
+            assert np.allclose(Lt, ref, rtol=1e-11, atol=1e-11), (group, tail_from, alone, np.abs(Lt - ref).max())
     tdist.barrier()
     tdist.destroy_process_group()
     sys.stdout.write("rank " + str(rank) + " ok" + chr(10))  # one write(): atomic on the shared pipe
@@ -76,7 +85,9 @@ WORKER = textwrap.dedent(
 )
 
 
-def test_two_rank_gloo_block_cyclic(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_gloo_block_cyclic(tmp_path, world):
+    """world 2: the contract's N > 1 case; world 3: the smallest job in which the tail's owner can keep out of the cyclic part."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
@@ -85,13 +96,13 @@ def test_two_rank_gloo_block_cyclic(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr",
                "127.0.0.1", "--master-port", str(port), str(script)]
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
         if out.returncode == 0:
             break
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert all("rank %d ok" % r in out.stdout for r in range(world))
 
 
 def test_socket_bootstrap_two_processes(tmp_path):

@@ -833,9 +833,10 @@ def test_block_cyclic_posterior_emulated_ranks(gpk, N, d, M, P, nb, group):
     np.testing.assert_allclose(var[0], cov_o, rtol=0, atol=RTOL * np.exp(lh[d]) ** 2)
 
 
-@pytest.mark.parametrize("N,P,group,tail_rows,chunk,fused", [(6000, 2, 2, 4096, 8, 0), (6000, 3, 2, 4096, 8, 0), (5000, 4, 1, 2048, 1, 0),
-                                                             (7000, 8, 2, 4096, 5, 0), (4000, 2, 2, 4096, 8, 2), (9000, 3, 4, 3072, 64, 0)])
-def test_block_cyclic_tail_block_is_bitwise_the_cyclic_schedule(gpk, N, P, group, tail_rows, chunk, fused):
+@pytest.mark.parametrize("N,P,group,tail_rows,chunk,fused,alone", [(6000, 2, 2, 4096, 8, 0, -1), (6000, 3, 2, 4096, 8, 0, -1), (5000, 4, 1, 2048, 1, 0, 0),
+                                                                   (7000, 8, 2, 4096, 5, 0, -1), (4000, 2, 2, 4096, 8, 2, 1), (9000, 3, 4, 3072, 64, 0, 0),
+                                                                   (5000, 4, 1, 2048, 8, 0, 1), (7000, 8, 2, 4096, 8, 2, 0), (9000, 5, 2, 2048, 8, 0, -1)])
+def test_block_cyclic_tail_block_is_bitwise_the_cyclic_schedule(gpk, N, P, group, tail_rows, chunk, fused, alone):
     """Round-3 verdict item 4(ii): the last tail_rows columns of a block-cyclic model are ONE tail block on one rank (gpk_model::ct),
     which factors it with the one-GPU tile pipeline (potrf_tail) and broadcasts the panels dist_tail_chunk at a time, instead of
     32 chain-bound panels changing hands one by one.  Same updates per element in the same order: bit for bit the cyclic
@@ -847,6 +848,7 @@ def test_block_cyclic_tail_block_is_bitwise_the_cyclic_schedule(gpk, N, P, group
     gpk.set_option("tail_rows", tail_rows)
     gpk.set_option("dist_tail_chunk", chunk)
     gpk.set_option("chain_fused", fused)
+    gpk.set_option("dist_tail_alone", alone)   # the tail's owner outside the cyclic part: by the work model (-1), never, whenever P >= 3
     L1 = np.empty((N, N))
     assert hooks().gpk_test_dist_potrf(_ptr(A), N, 1, _ptr(L1)) == 0, gpk.last_error()
     LP = np.empty((N, N))
@@ -854,6 +856,11 @@ def test_block_cyclic_tail_block_is_bitwise_the_cyclic_schedule(gpk, N, P, group
     assert gpk.get_option("dist_lookahead_used") == 1
     t = int(gpk.get_option("dist_tail_from"))
     assert t > 0
+    own = int(gpk.get_option("dist_tail_owner"))
+    if alone == 0 or P < 3:
+        assert 0 <= own < P
+    elif alone == 1:
+        assert own == 2 * P - 1   # rank P - 1, flagged as outside the cyclic map
     ob = 512 * ((group * 256 + 511) // 512)
     npad = -(-N // ob) * ob
     # the first ownership-block boundary (not the very first column) with at most tail_rows rows behind it
