@@ -35,7 +35,8 @@ static __device__ __forceinline__ double readlane_d(double v, int l) {
 // ds_bpermute pairs), factor the four columns with readlane broadcasts (6 updates instead of 54), one
 // v_mfma_f64_16x16x4_f64 for the whole trailing block.  ~100 instructions per four columns against ~240 for the
 // lane-per-row version with 15 readlane broadcasts per column (measured 18.5 vs 19.4 us per leaf: the chain of
-// dependent fp64 operations per pivot, not the instruction count, is what is left).
+// dependent fp64 operations per pivot, not the instruction count, is what is left -- round 4 took that chain from 17
+// dependent operations to 12, below: 18.4 -> 13.8 us per leaf).
 // Sb: element (0,0) of the block, LD: its row stride in doubles (the full-tile image of the 1024-thread leaf and the
 // block-triangular image of the slot-sized leaf share this code: same operations, same order, same bits).
 template <int LD>
@@ -58,20 +59,31 @@ static __device__ __forceinline__ void leaf_diag_block_mfma(double* Sb, int c0, 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const double piv = readlane_d(p[c], jb + c);
+      const double p2 = p[c] + p[c];  // (beside the root's chain, not on it)
       const bool ok = (piv > 1.0e-300) && (piv < 1.0e300);
       if (!ok && !bad) bad = jb + c + 1;
-      double y = __builtin_amdgcn_rsq(piv);
-      const double hp = 0.5 * piv;
-      y = __builtin_fma(y, __builtin_fma(-hp * y, y, 0.5), y);
-      y = __builtin_fma(y, __builtin_fma(-hp * y, y, 0.5), y);
-      double sq = piv * y;
-      sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, piv), sq);
-      l[c] = (r == jb + c) ? sq : ((r > jb + c) ? p[c] * y : 0.0);
-      if (lane == 0) rinvb[jb + c] = y;
+      // sqrt(piv) and 0.5 / sqrt(piv) by the coupled (Goldschmidt) iteration from v_rsq_f64: TWO dependent operations per step
+      // where the Newton form of rounds 1-3 had three, and the root itself comes with it instead of behind it; the column below
+      // the pivot and its broadcast to the next columns do not wait for the diagonal element either (`lo`: rows above the
+      // pivot hold values nobody reads -- every later use of p[c2] and of l[] masks them).  12 dependent operations per pivot
+      // against 17: 144 -> 108 ns, on every leaf of every chain step (full-tile leaf 49.4 -> 44.9 us, slot-sized 51.5 -> 46.8).
+      // Accuracy (scripts/leaf_accuracy.py): the root within 1 ulp, 1 / root within 2 ulp of the correctly rounded values over 16
+      // decades; residual of a dense tile 3e-16.
+      const double y0 = __builtin_amdgcn_rsq(piv);
+      double g = piv * y0, h = 0.5 * y0;
+      double e = __builtin_fma(-g, h, 0.5);
+      g = __builtin_fma(g, e, g);
+      h = __builtin_fma(h, e, h);
+      e = __builtin_fma(-g, h, 0.5);
+      g = __builtin_fma(g, e, g);
+      h = __builtin_fma(h, e, h);
+      const double lo = p2 * h;
+      l[c] = (r == jb + c) ? g : ((r > jb + c) ? lo : 0.0);
+      if (lane == 0) rinvb[jb + c] = h + h;
 #pragma unroll
       for (int c2 = c + 1; c2 < 4; ++c2) {
-        const double lkj = readlane_d(l[c], jb + c2);
-        p[c2] = __builtin_fma(-l[c], lkj, p[c2]);
+        const double lkj = readlane_d(lo, jb + c2);
+        p[c2] = __builtin_fma(-lo, lkj, p[c2]);
       }
     }
     if (lane < 16) {
