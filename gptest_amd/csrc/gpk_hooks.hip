@@ -580,11 +580,29 @@ int gpk_bench_se_build(int N, int d, int mode, int lower, int reps, double* ms_o
 // panels of other owners arrive as device copies from their models (the broadcasts' stand-in), never late.  ms_out[r]: the
 // time rank r needs when it never waits for a peer -- a LOWER bound of the job's time on P GPUs (max over r), and what one
 // GPU can measure of it.  ms_out[P]: the one-GPU posterior of the same problem in the same process.
+// comm_stream != 0: the panels of other owners arrive on a high-priority COMMUNICATION stream of their own, as on a real rank (update,
+// chain, substitution and communication stream: four), instead of sharing the substitution stream as in the test harness.
 int gpk_bench_dist_rank_alone(const double* X, const double* y, int N, int d, const double* log_hyp, const double* Z, int M, int P,
-                              int reps, double* ms_out) {
+                              int reps, int comm_stream, double* ms_out) {
   GPK_TRY(rt_require());
   if (!X || !y || !log_hyp || !Z || !ms_out || N < 1 || M < 1 || P < 2 || P > 16 || reps < 1)
     return gpk_set_err(-1, "gpk_bench_dist_rank_alone: bad arguments");
+  if (comm_stream && G.s_comm) return gpk_set_err(-1, "gpk_bench_dist_rank_alone: the process has a communication stream already");
+  struct TempComm {  // a real rank's fourth stream for the duration of the call
+    bool on = false;
+    ~TempComm() {
+      if (!on) return;
+      (void)hipStreamSynchronize(G.s_comm);
+      (void)hipStreamDestroy(G.s_comm);
+      G.s_comm = nullptr;
+    }
+  } tc;
+  if (comm_stream) {
+    int lo = 0, hi = 0;
+    GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    GPK_HIP(hipStreamCreateWithPriority(&G.s_comm, hipStreamNonBlocking, hi));
+    tc.on = true;
+  }
   hipStream_t s = G.s_main;
   VirtualJob job;
   GPK_TRY(job.create(N, d, P));

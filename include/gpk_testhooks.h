@@ -51,9 +51,10 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
 int gpk_bench_streams(int nstreams, int high_mask, int low_mask, int wgs, int us_each, int reps, int use_lib_streams, double* out_us);
 /* One rank of a P-rank block-cyclic posterior ALONE on the GPU (P virtual ranks in this process; the whole job runs once, then
  * each rank's share is replayed by itself `reps` times, panels of other owners arriving as device copies, never late):
- * ms_out[r] = the best time of rank r, r < P -- a lower bound of the P-GPU job's time, max over r. */
+ * ms_out[r] = the best time of rank r, r < P -- a lower bound of the P-GPU job's time, max over r.  comm_stream != 0: those copies
+ * on a communication stream of their own, the four-stream layout of a real rank (else they share the substitution stream). */
 int gpk_bench_dist_rank_alone(const double* X, const double* y, int N, int d, const double* log_hyp, const double* Z, int M, int P,
-                              int reps, double* ms_out);
+                              int reps, int comm_stream, double* ms_out);
 /* LDS banking probe for rocprofv3 --pmc (scripts/lds_bank_probe.sh): `reps` ds_read_b64 per lane in one of six address patterns. */
 int gpk_bench_lds_bank_probe(int pattern, int reps);
 /* leaf kernel timing; dbg_skip bit 0 = skip elimination, bit 1 = skip inverse (timing only), bit 8 = the full-tile form. */

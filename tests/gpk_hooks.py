@@ -27,7 +27,7 @@ def _bind(l):
         "gpk_test_dist_potrf": (i, [dp, i, i, dp]),
         "gpk_test_dist_fit": (i, [dp, i, i, dp, d, i, dp]),
         "gpk_test_dist_posterior": (i, [dp, dp, i, i, dp, dp, i, i, dp, dp, dp]),
-        "gpk_bench_dist_rank_alone": (i, [dp, dp, i, i, dp, dp, i, i, i, dp]),
+        "gpk_bench_dist_rank_alone": (i, [dp, dp, i, i, dp, dp, i, i, i, i, dp]),
         "gpk_bench_se_build": (i, [i, i, i, i, i, dp]),
         "gpk_bench_gemm_nt": (i, [i, i, i, i, i, i, dp]),
         "gpk_bench_lds_bank_probe": (i, [i, i]),
