@@ -113,7 +113,7 @@ void gpk_shutdown(void) {
   for (hipEvent_t e : G.ev_dep_free) (void)hipEventDestroy(e);
   G.ev_dep_free.clear();
   G.s_corner_prio = -1;
-  for (hipStream_t* sp : {&G.s_corner, &G.s_pred, &G.s_comm, &G.s_panel, &G.s_main}) {
+  for (hipStream_t* sp : {&G.s_near, &G.s_corner, &G.s_pred, &G.s_comm, &G.s_panel, &G.s_main}) {
     if (*sp) (void)hipStreamDestroy(*sp);
     *sp = nullptr;
   }
@@ -148,6 +148,8 @@ int gpk_set_option(const char* key, double value) {
   } else if (k == "dist_group") {
     if (v < 1 || v > 64) return gpk_set_err(-1, "dist_group must be in 1..64");
     G.dist_group = v;
+  } else if (k == "tail_stream") {
+    G.tail_stream = v ? 1 : 0;
   } else if (k == "kbuild_split") {
     G.kbuild_split = v ? 1 : 0;
   } else if (k == "se_scalar") {
@@ -226,6 +228,8 @@ double gpk_get_option(const char* key) {
   if (k == "dist_tail") return G.dist_tail;
   if (k == "se_scalar") return G.se_scalar;
   if (k == "kbuild_split") return G.kbuild_split;
+  if (k == "tail_stream") return G.tail_stream;
+  if (k == "tail_stream_used") return g_potrf_tail_stream;
   if (k == "kbuild_split_used") return g_kbuild_split;
   if (k == "dist_tail_chunk") return G.dist_tail_chunk;
   if (k == "dist_tail_alone") return G.dist_tail_alone;

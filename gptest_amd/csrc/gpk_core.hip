@@ -558,6 +558,14 @@ static int potrf_device_paired(gpk_model* m, const std::function<int(int)>* afte
 // What was tried on top of this and dropped (a stream of its own for the full-height GEMMs, the two one-tile GEMMs in one
 // launch, flag-chained steps without event packets, a resident leaf server): DESIGN.md section 6.
 static int span_update(gpk_model* m, int o_first, int o_last, int r0g, int c0g, int ncols, int lower, hipStream_t s, int persist_grid);
+int g_potrf_tail_stream = 0;  // 1 if the last tile pipeline ran its near GEMMs on the near stream
+static int near_stream_ensure() {
+  if (G.s_near) return 0;
+  int lo = 0, hi = 0;
+  GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  GPK_HIP(hipStreamCreateWithPriority(&G.s_near, hipStreamNonBlocking, hi));
+  return 0;
+}
 static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const std::function<int(int)>* after_panel) {
   hipStream_t sm = G.s_main, sc = G.s_panel;
   const int nP = m->nP, np_ = m->Npad;
@@ -566,9 +574,27 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
   hipEvent_t* ev_leaf = m->ev.data() + 3 * nP + 6;
   hipEvent_t* ev_tt = m->ev.data() + 4 * nP + 6;
   hipEvent_t* ev_near = m->ev.data() + 5 * nP + 6;
+  hipEvent_t* ev_far = m->ev.data() + 6 * nP + 6;
   if (ev_prev_rest) GPK_HIP(hipStreamWaitEvent(sm, ev_prev_rest, 0));
   // one launch per chain step (potf2_chain_kernel) where the full-tile leaf is used and cross-stream flags work
   const bool fused_ok = (G.chain_fused > 0 || (G.chain_fused < 0 && G.flags_ok)) && m->dflags;
+  // The NEAR stream (option tail_stream): the full-height solve and the look-ahead update of tile columns p+1, p+2 -- what the
+  // chain waits for next -- on a stream of their own instead of in front of the bulk on the update stream, where they queue
+  // behind REST(p-1) (35 us at 4096 rows).  A fourth stream that does not share a hardware queue with one of the other three has
+  // to be a HIGH-priority one on this runtime (profiles/r04_stream_probe_null.txt), and a fifth never fits: not in a process with
+  // a communication stream.  Hazards across the two streams: near(p) writes tile columns p+1, p+2, whose earlier writers on the
+  // update stream -- REST(p-3), REST(p-2), LAfar(p-2), LAfar(p-1) -- all precede the event `far(p-1)` recorded behind LAfar(p-1);
+  // LAfar(p) and REST(p) read rows of panel p that the solve on the near stream writes: they wait for near(p).
+  hipStream_t sn = sm;
+  if (G.tail_stream && !G.s_comm && !fused_ok) {
+    GPK_TRY(near_stream_ensure());
+    sn = G.s_near;
+    hipEvent_t ev_in = m->ev[2 * nP + 1];  // everything queued on the update stream so far (the hand-over's updates)
+    GPK_HIP(hipEventRecord(ev_in, sm));
+    GPK_HIP(hipStreamWaitEvent(sn, ev_in, 0));
+  }
+  g_potrf_tail_stream = sn != sm ? 1 : 0;
+  const bool near_on = sn != sm;
   const unsigned epoch = ++G.flag_epoch;
   g_potrf_chain_fused = 0;
   for (int p = p_first; p < nP; ++p) {
@@ -619,7 +645,8 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       GPK_HIP(hipEventRecord(ev_tt[p], sc));
     }
     // ---- full-height panel GEMMs, in front of the bulk on the update stream
-    if (!early) GPK_HIP(hipStreamWaitEvent(sm, h <= 128 ? ev_leaf[p] : ev_tt[p], 0));
+    if (!early) GPK_HIP(hipStreamWaitEvent(sn, h <= 128 ? ev_leaf[p] : ev_tt[p], 0));
+    if (sn != sm && p > p_first) GPK_HIP(hipStreamWaitEvent(sn, ev_far[p - 1], 0));
     if (h > 256) {
       GemmNT g{};  // SOLVE(p): rows from tile p+2
       g.A = Acol + (long)256 * ldk; g.lda = ldk;
@@ -627,13 +654,13 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       g.C = Lp + (long)256 * ld; g.ldc = ld;
       g.m = h - 256; g.n = 128; g.k = 128; g.sub = 0;
       if (early) { g.wait_flag = m->dflags + m->nT + p; g.wait_val = epoch; g.wait_info = m->dinfo; }
-      GPK_TRY(launch_gemm_nt(g, false, sm));
+      GPK_TRY(launch_gemm_nt(g, false, sn));
     }
     if (early && h <= 256) GPK_HIP(hipStreamWaitEvent(sm, ev_tt[p], 0));  // (no polling launch in this step: the event after all)
     // every row of panel p is in place (early: not before the look-ahead update below, which is what has waited for L(p+1,p))
     auto panel_done = [&]() -> int {
-      GPK_HIP(hipEventRecord(ev_panel[p], sm));
-      if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sm));
+      GPK_HIP(hipEventRecord(ev_panel[p], sn));
+      if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sn));
       if (after_panel) GPK_TRY((*after_panel)(p));
       return 0;
     };
@@ -646,10 +673,11 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       g.C = Acol + (long)256 * ldk + 128; g.ldc = ldk;
       g.m = h - 256; g.n = std::min(256, h - 128); g.k = 128; g.sub = 1;
       if (early) { g.wait_flag = m->dflags + 2 * m->nT + p; g.wait_val = epoch; g.wait_info = m->dinfo; }
-      GPK_TRY(launch_gemm_nt(g, false, sm));
+      GPK_TRY(launch_gemm_nt(g, false, sn));
     }
     if (late_panel_event) GPK_TRY(panel_done());
-    GPK_HIP(hipEventRecord(ev_near[p], sm));
+    GPK_HIP(hipEventRecord(ev_near[p], sn));
+    if (sn != sm) GPK_HIP(hipStreamWaitEvent(sm, ev_near[p], 0));  // LAfar(p), REST(p) read the rows the solve has written (and the update stream joins the near stream step by step)
     if (fused_ok && h > 256) GPK_TRY(launch_flag_set(m->dflags + p, epoch, sm));  // what the fused step p+1 polls
     if (h > 384) {
       GemmNT g{};  // LAfar(p): tile column p+3, rows from tile p+3
@@ -659,6 +687,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
       g.m = h - 384; g.n = 128; g.k = 128; g.sub = 1; g.lower = 1;
       GPK_TRY(launch_gemm_nt(g, false, sm));
     }
+    if (sn != sm) GPK_HIP(hipEventRecord(ev_far[p], sm));
     // ---- bulk
     if (h > 512) {
       const int r1 = c0 + 512;

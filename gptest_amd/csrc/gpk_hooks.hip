@@ -334,7 +334,8 @@ int gpk_bench_streams(int nstreams, int high_mask, int low_mask, int wgs, int us
   std::vector<bool> own(nstreams, true);
   hipStream_t lib[3] = {G.s_main, G.s_panel, G.s_pred};
   for (int i = 0; i < nstreams; ++i) {
-    if (use_lib_streams && i < 3 && lib[i]) { st[i] = lib[i]; own[i] = false; continue; }
+    if ((use_lib_streams & 1) && i < 3 && lib[i]) { st[i] = lib[i]; own[i] = false; continue; }
+    if ((use_lib_streams & 2) && i == nstreams - 1) { st[i] = nullptr; own[i] = false; continue; }  // the LAST stream is the null stream
     const int pr = (high_mask >> i) & 1 ? hi : ((low_mask >> i) & 1 ? lo : (lo + hi) / 2);
     GPK_HIP(hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, pr));
   }
