@@ -581,7 +581,7 @@ static int near_stream_ensure() {
 // the previous batch (event `sm_batch`); the update stream waits for panel[p] before WINb(p).
 int g_potrf_tail_batch = 0;  // R of the last batched tile pipeline (0: not batched)
 static int potrf_tail_batched(gpk_model* m, int p_first, int R, const std::function<int(int)>* after_panel) {
-  hipStream_t sm = G.s_main, sc = G.s_panel, sn = G.s_near;
+  hipStream_t sm = G.s_main, sc = G.s_panel, sn = G.tail_stream ? G.s_near : G.s_pred;
   const int nP = m->nP, np_ = m->Npad;
   const long ldk = m->ldk;
   hipEvent_t* ev_panel = m->ev.data();
@@ -595,7 +595,7 @@ static int potrf_tail_batched(gpk_model* m, int p_first, int R, const std::funct
     GPK_HIP(hipEventRecord(ev_in, sm));
     GPK_HIP(hipStreamWaitEvent(sn, ev_in, 0));
   }
-  g_potrf_tail_stream = 1;
+  g_potrf_tail_stream = G.tail_stream ? 1 : 0;
   g_potrf_tail_batch = R;
   g_potrf_chain_fused = 0;
   for (int p = p_first; p < nP; ++p) {
@@ -645,7 +645,6 @@ static int potrf_tail_batched(gpk_model* m, int p_first, int R, const std::funct
     }
     GPK_HIP(hipEventRecord(ev_panel[p], sn));
     if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sn));
-    if (after_panel) GPK_TRY((*after_panel)(p));
     if (h > 256) {
       GemmNT g{};  // LAnear(p): tile columns p+1, p+2, rows from tile p+2
       g.A = Lp + (long)256 * ld; g.lda = ld;
@@ -659,6 +658,7 @@ static int potrf_tail_batched(gpk_model* m, int p_first, int R, const std::funct
       const int ca = colof(p + 3), cb = colof(f_prev);  // WINa(p)
       if (cb > ca) GPK_TRY(panel_update(m, p, ca, ca, cb - ca, 1, sn));
     }
+    if (after_panel) GPK_TRY((*after_panel)(p));  // (behind what the chain waits for: the near stream may be the substitution stream)
     // ---- update stream
     GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
     {
@@ -712,8 +712,8 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
   }
   g_potrf_tail_stream = sn != sm ? 1 : 0;
   g_potrf_tail_batch = 0;
-  if (G.tail_batch > 0 && !G.s_comm && !fused_ok && !ev_prev_rest && nP - p_first > G.tail_batch + 3) {
-    GPK_TRY(near_stream_ensure());
+  if (G.tail_batch > 0 && !G.s_comm && G.s_pred && !fused_ok && !ev_prev_rest && nP - p_first > G.tail_batch + 3) {
+    if (G.tail_stream) GPK_TRY(near_stream_ensure());
     return potrf_tail_batched(m, p_first, G.tail_batch, after_panel);
   }
   const unsigned epoch = ++G.flag_epoch;
@@ -1634,7 +1634,10 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp) {
     }
   }
   const auto host_t0 = std::chrono::steady_clock::now();
-  const int prc = potrf_device(m);
+  // (batched tile pipeline with the substitution stream as its near stream: panel p's substitutions are queued right behind panel p's
+  // near launches -- after the whole factorisation they would only start when the last near launch has run)
+  const bool interleave = pipelined && G.tail_batch > 0 && !G.tail_stream;
+  const int prc = potrf_device(m, interleave ? &hook : nullptr);
   m->ev_kfirst = nullptr;
   GPK_TRY(prc);
   G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
@@ -1644,7 +1647,7 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp) {
   const auto host_t1 = std::chrono::steady_clock::now();
   if (pipelined) {
     if (!g_potrf_lookahead_used) return gpk_set_err(-1, "internal: pipelined substitutions without look-ahead");
-    for (int p = 0; p < m->nP; ++p) GPK_TRY(hook(p));
+    for (int p = 0; p < m->nP && !interleave; ++p) GPK_TRY(hook(p));
     if (fuse) {
       timer_end("predict", sq);
       fused_done = true;
