@@ -150,9 +150,6 @@ int gpk_set_option(const char* key, double value) {
     G.dist_group = v;
   } else if (k == "tail_stream") {
     G.tail_stream = v ? 1 : 0;
-  } else if (k == "tail_batch") {
-    if (v < 0 || v > GPK_MAXSEG) return gpk_set_err(-1, "tail_batch %d outside 0..%d", (int)v, GPK_MAXSEG);
-    G.tail_batch = (int)v;
   } else if (k == "kbuild_split") {
     G.kbuild_split = v ? 1 : 0;
   } else if (k == "se_scalar") {
@@ -233,8 +230,6 @@ double gpk_get_option(const char* key) {
   if (k == "kbuild_split") return G.kbuild_split;
   if (k == "tail_stream") return G.tail_stream;
   if (k == "tail_stream_used") return g_potrf_tail_stream;
-  if (k == "tail_batch") return G.tail_batch;
-  if (k == "potrf_tail_batch") return g_potrf_tail_batch;
   if (k == "kbuild_split_used") return g_kbuild_split;
   if (k == "dist_tail_chunk") return G.dist_tail_chunk;
   if (k == "dist_tail_alone") return G.dist_tail_alone;

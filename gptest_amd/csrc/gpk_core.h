@@ -44,7 +44,6 @@ struct Runtime {
   int dist_tail = 1;      // block-cyclic models: the last tail_rows columns as one tail block on one rank, factored there by the tile pipeline
   int tail_stream = 0;    // tile pipeline: the full-height solve and the look-ahead update of a step on a (high-priority) stream of their own (OFF: bit-identical, measured slower -- N=4096 2.79 -> 3.08-3.22 ms, 8192 7.78 -> 7.95, 16384 32.9 -> 33.2: profiles/r04_tail_stream_ab.txt)
   hipStream_t s_near = nullptr;
-  int tail_batch = 0;     // tile pipeline in batches of this many steps (potrf_tail_batched): near stream for everything the chain needs soon, the far update of a batch as ONE K = 128 R launch on the update stream; 0: off
   int kbuild_split = 0;   // fused one-GPU fits: K's first block column as a launch of its own, so that panel 0 is factored beside the rest of the build (OFF: the build's waves fill every SIMD and panel 0 takes 0.58 instead of 0.41 ms beside it -- 20 us gained, none in the posterior)
   int se_scalar = 1;      // K / Kxz builds of models with d <= 8 in the scalar-operand form (SEScalarForm; 0: the LDS form, same bits)
   int dist_tail_alone = -1; // the tail's owner keeps out of the cyclic part (gpk_model::Pc): -1 where the work model says so, 0 never, 1 whenever P >= 3
@@ -269,7 +268,6 @@ int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* 
 // fit + sharded prediction in one go: the y and prediction substitutions pipelined behind the per-panel events of the block-cyclic factorisation
 int fit_predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var);
 extern int g_dist_tail_from;        // first panel the last block-cyclic factorisation ran through the tile pipeline on the tail's owner (-1: none)
-extern int g_potrf_tail_batch;      // R of the last batched tile pipeline (0: none)
 extern int g_potrf_tail_stream;     // 1 if the last tile pipeline used the near stream
 extern int g_kbuild_split;          // 1 if the last fused fit built K in two launches (first block column, rest)
 extern int g_dist_tail_owner;       // ... its owner; P + owner if that rank keeps out of the cyclic part

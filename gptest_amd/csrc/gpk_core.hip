@@ -566,123 +566,6 @@ static int near_stream_ensure() {
   GPK_HIP(hipStreamCreateWithPriority(&G.s_near, hipStreamNonBlocking, hi));
   return 0;
 }
-// The tile pipeline in BATCHES of R steps (option tail_batch = R, needs the near stream): the chain stream keeps leaf + two one-tile
-// GEMMs per step, the near stream (high priority, the fourth stream that does run abreast: profiles/r04_stream_probe_null.txt) the
-// full-height solve and every update the chain needs SOON, the update stream nothing but bulk -- so the pipeline can start
-// where the trailing matrix is still large (tail_rows = 8704 at N = 16384) without its K = 128 far updates becoming the bound.
-// With e(k) the first panel behind batch k and f(k) = e(k) + R + 3 (panel = tile column indices):
-//   near stream, step p of batch k:  SOLVE(p), LAnear(p) (tile columns p+1, p+2), WINa(p): columns [p+3, f(k-1)) at K = 128
-//   update stream:                   WINb(p): columns [f(k-1), f(k)) at K = 128, behind far(k-1); after the batch's last step
-//                                    far(k): the lower square from column f(k), ONE launch with K = 128 R over a segment table
-// far(k) has the R steps of batch k+1 to finish: nothing batch k+1 does on the chain or the near stream touches a column >= f(k).
-// A column j in [f(k-1), f(k)) is written, in this order, by the hand-over, far(0..k-1), WINb (batch k), WINa (batch k+1),
-// LAnear and T: the same rank-128 updates in panel order as in potrf_tail, inside MFMA chains that start from the stored value
-// -- the same bits (tests).  Cross-stream hazards: the near stream waits at every batch start for the update stream's WINb of
-// the previous batch (event `sm_batch`); the update stream waits for panel[p] before WINb(p).
-int g_potrf_tail_batch = 0;  // R of the last batched tile pipeline (0: not batched)
-static int potrf_tail_batched(gpk_model* m, int p_first, int R, const std::function<int(int)>* after_panel) {
-  hipStream_t sm = G.s_main, sc = G.s_panel, sn = G.tail_stream ? G.s_near : G.s_pred;
-  const int nP = m->nP, np_ = m->Npad;
-  const long ldk = m->ldk;
-  hipEvent_t* ev_panel = m->ev.data();
-  hipEvent_t* ev_leaf = m->ev.data() + 3 * nP + 6;
-  hipEvent_t* ev_tt = m->ev.data() + 4 * nP + 6;
-  hipEvent_t* ev_near = m->ev.data() + 5 * nP + 6;
-  hipEvent_t* ev_smb = m->ev.data() + 6 * nP + 6;  // per batch: the update stream has applied the batch's WINb
-  auto colof = [&](int q) { return q < nP ? m->pc0[q] : np_; };
-  {
-    hipEvent_t ev_in = m->ev[2 * nP + 1];  // everything queued on the update stream so far (the hand-over's updates)
-    GPK_HIP(hipEventRecord(ev_in, sm));
-    GPK_HIP(hipStreamWaitEvent(sn, ev_in, 0));
-  }
-  g_potrf_tail_stream = G.tail_stream ? 1 : 0;
-  g_potrf_tail_batch = R;
-  g_potrf_chain_fused = 0;
-  for (int p = p_first; p < nP; ++p) {
-    const int t = p - p_first, k = t / R;
-    const int e_k = std::min(nP, p_first + (k + 1) * R);        // first panel behind the batch
-    const int f_prev = std::min(nP, p_first + (k + 1) * R + 3);  // f(k-1): WINa below it, WINb from it
-    const int f_k = std::min(nP, p_first + (k + 2) * R + 3);     // f(k): far(k) from it
-    const int c0 = m->pc0[p], h = np_ - c0;
-    const long ld = m->pld[p];
-    double* Lp = m->Lpanel(p);
-    double* Acol = m->dK + (long)c0 * ldk + m->local_col(c0);
-    double* Dt = m->dDinv + (long)(c0 / 128) * 128 * 128;
-    // ---- chain stream
-    GPK_TRY(leaf_launch(Acol, ldk, Lp, ld, Dt, m->dinfo, c0, sc, h));
-    if (h <= 128) GPK_HIP(hipEventRecord(ev_leaf[p], sc));
-    if (h > 128) {
-      if (p > p_first) GPK_HIP(hipStreamWaitEvent(sc, ev_near[p - 1], 0));
-      GemmNT t1{};  // L(p+1,p) = A(p+1,p) Dinv^T
-      t1.A = Acol + (long)128 * ldk; t1.lda = ldk;
-      t1.B = Dt; t1.ldb = 128;
-      t1.C = Lp + (long)128 * ld; t1.ldc = ld;
-      t1.m = 128; t1.n = 128; t1.k = 128; t1.sub = 0;
-      GemmNT t2{};  // A(p+1,p+1) -= L(p+1,p) L(p+1,p)^T
-      t2.A = Lp + (long)128 * ld; t2.lda = ld;
-      t2.B = t2.A; t2.ldb = ld;
-      t2.C = Acol + (long)128 * ldk + 128; t2.ldc = ldk;
-      t2.m = 128; t2.n = 128; t2.k = 128; t2.sub = 1; t2.lower = 1;
-      if (G.tail_tile_kernel > 0 || (G.tail_tile_kernel < 0 && np_ < 12288)) {
-        GPK_TRY(launch_gemm_tile128(t1, sc));
-        GPK_TRY(launch_gemm_tile128(t2, sc));
-      } else {
-        GPK_TRY(launch_gemm_nt(t1, false, sc));
-        GPK_TRY(launch_gemm_nt(t2, false, sc));
-      }
-      GPK_HIP(hipEventRecord(ev_tt[p], sc));
-    }
-    // ---- near stream
-    GPK_HIP(hipStreamWaitEvent(sn, h <= 128 ? ev_leaf[p] : ev_tt[p], 0));
-    if (t % R == 0 && k > 0) GPK_HIP(hipStreamWaitEvent(sn, ev_smb[k - 1], 0));
-    if (h > 256) {
-      GemmNT g{};  // SOLVE(p): rows from tile p+2
-      g.A = Acol + (long)256 * ldk; g.lda = ldk;
-      g.B = Dt; g.ldb = 128;
-      g.C = Lp + (long)256 * ld; g.ldc = ld;
-      g.m = h - 256; g.n = 128; g.k = 128; g.sub = 0;
-      GPK_TRY(launch_gemm_nt(g, false, sn));
-    }
-    GPK_HIP(hipEventRecord(ev_panel[p], sn));
-    if (G.stamps && G.dstamps) GPK_TRY(launch_stamp(G.dstamps + p, sn));
-    if (h > 256) {
-      GemmNT g{};  // LAnear(p): tile columns p+1, p+2, rows from tile p+2
-      g.A = Lp + (long)256 * ld; g.lda = ld;
-      g.B = Lp + (long)128 * ld; g.ldb = ld;
-      g.C = Acol + (long)256 * ldk + 128; g.ldc = ldk;
-      g.m = h - 256; g.n = std::min(256, h - 128); g.k = 128; g.sub = 1;
-      GPK_TRY(launch_gemm_nt(g, false, sn));
-    }
-    GPK_HIP(hipEventRecord(ev_near[p], sn));
-    {
-      const int ca = colof(p + 3), cb = colof(f_prev);  // WINa(p)
-      if (cb > ca) GPK_TRY(panel_update(m, p, ca, ca, cb - ca, 1, sn));
-    }
-    if (after_panel) GPK_TRY((*after_panel)(p));  // (behind what the chain waits for: the near stream may be the substitution stream)
-    // ---- update stream
-    GPK_HIP(hipStreamWaitEvent(sm, ev_panel[p], 0));
-    {
-      const int ca = colof(std::max(f_prev, p + 3)), cb = colof(f_k);  // WINb(p)
-      if (cb > ca) GPK_TRY(panel_update(m, p, ca, ca, cb - ca, 1, sm));
-    }
-    if (p + 1 == e_k) {
-      GPK_HIP(hipEventRecord(ev_smb[k], sm));
-      const int r1 = colof(f_k);
-      if (np_ - r1 > 0) {  // far(k)
-        const int pf = p_first + k * R;
-        int kspan = 0;
-        for (int q = pf; q <= p; ++q) kspan += m->pw[q];
-        const long nt = (np_ - r1) / 128;
-        const char* tname = (nt * (nt + 1) / 2 < G.small_tile_below) ? "trailing_small" : "trailing";
-        timer_begin(tname, sm, (double)(np_ - r1) * (np_ - r1) * kspan);
-        GPK_TRY(span_update(m, m->pouter[pf], m->pouter[p], r1, r1, np_ - r1, 1, sm, 0));
-        timer_end(tname, sm);
-      }
-    }
-  }
-  return 0;
-}
-
 static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const std::function<int(int)>* after_panel) {
   hipStream_t sm = G.s_main, sc = G.s_panel;
   const int nP = m->nP, np_ = m->Npad;
@@ -711,11 +594,7 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
     GPK_HIP(hipStreamWaitEvent(sn, ev_in, 0));
   }
   g_potrf_tail_stream = sn != sm ? 1 : 0;
-  g_potrf_tail_batch = 0;
-  if (G.tail_batch > 0 && !G.s_comm && G.s_pred && !fused_ok && !ev_prev_rest && nP - p_first > G.tail_batch + 3) {
-    if (G.tail_stream) GPK_TRY(near_stream_ensure());
-    return potrf_tail_batched(m, p_first, G.tail_batch, after_panel);
-  }
+  const bool near_on = sn != sm;
   const unsigned epoch = ++G.flag_epoch;
   g_potrf_chain_fused = 0;
   for (int p = p_first; p < nP; ++p) {
@@ -1634,10 +1513,7 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp) {
     }
   }
   const auto host_t0 = std::chrono::steady_clock::now();
-  // (batched tile pipeline with the substitution stream as its near stream: panel p's substitutions are queued right behind panel p's
-  // near launches -- after the whole factorisation they would only start when the last near launch has run)
-  const bool interleave = pipelined && G.tail_batch > 0 && !G.tail_stream;
-  const int prc = potrf_device(m, interleave ? &hook : nullptr);
+  const int prc = potrf_device(m);
   m->ev_kfirst = nullptr;
   GPK_TRY(prc);
   G.last_potrf_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
@@ -1647,7 +1523,7 @@ static int fit_enqueue(gpk_model* m, const FusedPredict* fp) {
   const auto host_t1 = std::chrono::steady_clock::now();
   if (pipelined) {
     if (!g_potrf_lookahead_used) return gpk_set_err(-1, "internal: pipelined substitutions without look-ahead");
-    for (int p = 0; p < m->nP && !interleave; ++p) GPK_TRY(hook(p));
+    for (int p = 0; p < m->nP; ++p) GPK_TRY(hook(p));
     if (fuse) {
       timer_end("predict", sq);
       fused_done = true;

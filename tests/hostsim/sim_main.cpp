@@ -81,30 +81,6 @@ int main() {
   }
   opt("chain_fused", 0);
   check_fit_predict(make_problem(300, 1, 5), "tile pipeline, three tiles");
-  {  // batched tile pipeline (near stream; far updates of a batch as one K-segment launch): the factor of the plain pipeline, exactly
-    auto spdm = [](int N) {
-      vec A((size_t)N * N);
-      for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) { const double v = (i == j ? N + 1.0 : 0.0) + std::cos(0.07 * (i - j)); A[(size_t)i * N + j] = A[(size_t)j * N + i] = v; }
-      return A;
-    };
-    for (int N : {900, 1700, 2100}) {
-      const vec A = spdm(N);
-      vec L0 = A;
-      opt("tail_batch", 0);
-      CHECK(gpk_potrf(L0.data(), N) == 0 && gpk_get_option("potrf_tail_batch") == 0, "plain tile pipeline N=%d", N);
-      for (int R : {1, 2, 3, 4, 8}) {
-        opt("tail_batch", R);
-        vec L1 = A;
-        CHECK(gpk_potrf(L1.data(), N) == 0, "batched tile pipeline N=%d R=%d", N, R);
-        const bool used = (N + 127) / 128 > R + 3;
-        CHECK(gpk_get_option("potrf_tail_batch") == (used ? R : 0), "batched tile pipeline N=%d R=%d used: %g", N, R, gpk_get_option("potrf_tail_batch"));
-        CHECK(maxdiff(L0, L1) == 0.0, "batched tile pipeline N=%d R=%d: diff %g", N, R, maxdiff(L0, L1));
-      }
-    }
-    opt("tail_batch", 4);
-    check_fit_predict(make_problem(1400, 2, 30), "batched tile pipeline, whole posterior");
-    opt("tail_batch", 0);
-  }
   opt("tail_rows", 0); opt("nb", 0);
   opt("nb_outer", 2048); opt("outer_until", 8192); opt("nb_big_until", 8192); opt("nb_small_from", 2048);
 

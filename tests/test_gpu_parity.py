@@ -376,28 +376,23 @@ def test_tile_pipeline_tail_is_bitwise_the_panel_schedule(gpk, N, opts, tail_fro
     assert gpk.get_option("flags_ok") == 1  # (the plain runtime lets a running kernel see another stream's later flag)
     # 1: leaf + two one-tile kernels per step, 2: one launch per step (potf2_chain_kernel), 3: ... whose flags the update stream polls,
     # 4: as 1 with the full-height solve and the look-ahead update on the near stream (option tail_stream)
-    # 5, 6: the batched pipeline (option tail_batch = 2 / 4: far updates of a batch as one K-segment launch; near launches on the
-    # substitution stream), 7: ... on the near stream
-    for tail in (0, 1, 2, 3, 4, 5, 6, 7):
+    for tail in (0, 1, 2, 3, 4):
         for k, v in opts.items():
             gpk.set_option(k, 0 if (k == "tail_rows" and not tail) else v)
         gpk.set_option("pair_update", 0)
         gpk.set_option("chain_fused", max(tail - 1, 0) if tail < 4 else 0)
-        gpk.set_option("tail_stream", 1 if tail in (4, 7) else 0)
-        gpk.set_option("tail_batch", {5: 2, 6: 4, 7: 3}.get(tail, 0))
+        gpk.set_option("tail_stream", 1 if tail == 4 else 0)
         L = A.copy()
         assert gpk.lib().gpk_potrf(_ptr(L), N) == 0, gpk.last_error()
         tf = gpk.get_option("potrf_tail_from")
         if tail:
             assert tf >= 0 and (tail_from is None or tf == tail_from)
             assert (gpk.get_option("potrf_chain_fused") > 0) == (tail in (2, 3))
-            batched = gpk.get_option("potrf_tail_batch")
-            assert batched in ((0, {5: 2, 6: 4, 7: 3}[tail]) if tail >= 5 else (0,))
-            assert gpk.get_option("tail_stream_used") == (1 if tail in (4, 7) else 0)
+            assert gpk.get_option("tail_stream_used") == (1 if tail == 4 else 0)
         else:
             assert tf == -1
         out.append(L)
-    for k in range(1, 8):
+    for k in range(1, 5):
         np.testing.assert_array_equal(out[0], out[k])
     Lr = np.linalg.cholesky(A)
     np.testing.assert_allclose(out[1], Lr, rtol=1e-11, atol=1e-11 * np.abs(Lr).max())
