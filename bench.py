@@ -185,6 +185,59 @@ def phase_split(l, _lib, X, y, Z, lh, N, d, M):
         l.gpk_set_option(b"stamps", 0.0)
 
 
+def secondary_configs(l, _lib):
+    """BASELINE.json's other one-GPU configurations, measured after the headline's timed region so that the driver's record
+    carries them too (about 1.5 s): configs[1] (GPr N=4096 d=4, parity against its committed fixture) and configs[4] (the
+    preference Laplace loop at 8192 pairs, d=4; inputs shaped like GP_preference_demo.py:39-44, as scripts/secondary_numbers.py).
+    Event timers off: these are plain wall-clock / device-event figures of the default schedule."""
+    from gptest_amd import GPpref
+
+    P = _lib.c_double_p
+    _lib.check(l.gpk_set_option(b"timing", 0.0), "timing")
+    out = {}
+    N, d, M = 4096, 4, 1024
+    X, y, Z, lh = synthetic_problem(N, d, M)
+    ms, nl = ctypes.c_double(), ctypes.c_double()
+    mean, var = np.zeros(M), np.zeros(M)
+    steps = 40
+    _lib.check(l.gpk_bench_posterior(X.ctypes.data_as(P), y.ctypes.data_as(P), N, d, lh.ctypes.data_as(P), Z.ctypes.data_as(P), M, 5, steps,
+                                     ctypes.byref(ms), ctypes.byref(nl), mean.ctypes.data_as(P), var.ctypes.data_as(P)), "configs[1]")
+    checked, detail, ok = parity_check(N, d, M, nl.value, mean, var, lh)
+    flop = N ** 3 / 3.0 + float(M) * N * N
+    out["configs_1"] = {"workload": "GPr regression N=4096 d=4 RBF fp64, M=1024 (BASELINE configs[1])", "value": steps / (ms.value * 1e-3),
+                        "unit": "posteriors/s", "ms_per_step": ms.value / steps, "steps": steps, "parity_checked": checked, "parity": detail,
+                        "tflops_whole_posterior": flop / (ms.value / steps * 1e-3) / 1e12,
+                        "note": "latency-bound size: 32 dependent leaf steps of ~85 us (DESIGN.md section 6); N^3/3 + M N^2 flops per posterior"}
+    if not ok:
+        raise RuntimeError("configs[1] parity failure: %r" % (detail,))
+    rng = np.random.RandomState(1)
+    npairs, d = 8192, 4
+    x = rng.random_sample((2 * npairs, d))
+    uvi = rng.choice(2 * npairs, (npairs, 2), replace=False)
+    fx = np.sin(2.0 * np.pi * x.mean(axis=1)) + 0.05 * rng.randn(2 * npairs)
+    yp = np.where(fx[uvi[:, 1]] > fx[uvi[:, 0]], 1.0, -1.0).reshape(-1, 1)
+    lhp = np.log([0.3] * d + [1.0, 0.1])
+    gp = GPpref.PreferenceGaussianProcess(x, uvi, yp, delta_f=1e-6)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        f, lml = gp.calc_laplace(lhp)
+        t = time.perf_counter() - t0
+        best = t if best is None else min(best, t)
+    nx, it = 2 * npairs, gp.last_iterations
+    flop = nx ** 3 / 3.0 + it * npairs ** 3 / 3.0
+    byts = it * (2 * 8.0 * nx * nx + 16.0 * npairs * npairs)
+    out["configs_4"] = {"workload": "GPpref preference Laplace loop, 8192 pairs (nx = 16384), d=4 (BASELINE configs[4]); calc_laplace through the Python surface, host buffers in and out",
+                        "ms_per_loop": best * 1e3, "value": 1.0 / best, "unit": "Laplace fits/s", "newton_iterations": it, "converged": bool(gp.last_converged),
+                        "lml": float(lml),
+                        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP64_MFMA_TFLOPS, "achieved": flop / best / 1e12, "frac": flop / best / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                                     "flop": flop, "hbm_bytes_gemv_and_build_B": byts, "hbm_ms_at_peak": byts / (PEAK_HBM_GBS * 1e9) * 1e3,
+                                     "note": "one Cholesky of K + eps I at nx (nx^3/3) and per Newton iteration one of B = I + C^1/2 (D K D^T) C^1/2 at npairs (npairs^3/3), "
+                                             "two GEMVs with the kept K (8 nx^2 B each) and the build of B (16 npairs^2 B); both factorisations are chain-bound sizes"},
+                        "parity": "unpinned (the reference's GPpref.py is Python 2 + GPy and holds no fixture; tests compare with oracle/gppref_oracle.py)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +250,7 @@ def main():
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="skip roofline.sustained (its 24 extra update launches would be counted by the kernel-trace / PMC scripts)")
     ap.add_argument("--no-phases", action="store_true", help="skip roofline.phases (one extra posterior with device stamps after the timed region)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (BASELINE configs[1] and configs[4], ~1.5 s after the timed region)")
     ap.add_argument("--opt", action="append", default=[], help="libgpk option key=value (experiments; defaults are the product)")
     args = ap.parse_args()
 
@@ -369,6 +423,11 @@ def main():
             "parity": parity_detail,
             "wall_s_incl_staging": wall,
         }
+        if world == 1 and not args.no_secondary and (N, d, M) == (16384, 8, 1024):
+            try:
+                out["secondary"] = secondary_configs(l, _lib)
+            except Exception as e:  # never lose the headline over a secondary figure
+                out["secondary"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would idle in the barrier
             out["cpu_baseline"] = cpu_baseline(N, d, M)
         if parity_ok:

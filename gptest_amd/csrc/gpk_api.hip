@@ -163,7 +163,8 @@ int gpk_set_option(const char* key, double value) {
     if (v < 1 || v > 64) return gpk_set_err(-1, "gpk_set_option: dist_tail_chunk must be 1..64");
     G.dist_tail_chunk = (int)v;
   } else if (k == "dist_pipeline") {
-    G.dist_pipeline = v ? 1 : 0;
+    if (v < 0 || v > 2) return gpk_set_err(-1, "gpk_set_option: dist_pipeline must be 0, 1 or 2");
+    G.dist_pipeline = (int)v;
   } else if (k == "tail_rows") {
     G.tail_rows = v;
   } else if (k == "leaf_fat_rows") {  // the full-tile leaf once at most this many rows remain; -1: never, 1 << 30: always
@@ -225,6 +226,8 @@ double gpk_get_option(const char* key) {
   if (k == "lookahead") return G.lookahead;
   if (k == "dist_group") return G.dist_group;
   if (k == "dist_pipeline") return G.dist_pipeline;
+  if (k == "dist_streams_abreast") return g_dist_streams_abreast;
+  if (k == "dist_streams_worst_us") return g_dist_streams_worst_us;
   if (k == "dist_tail") return G.dist_tail;
   if (k == "se_scalar") return G.se_scalar;
   if (k == "kbuild_split") return G.kbuild_split;

@@ -40,6 +40,42 @@ int gpk_comm_unique_id(void* out128) {
   return 0;
 }
 
+}  // extern "C"
+
+// Do these streams run ABREAST?  `reps` rounds of one spinning wave (10 us) on each, queued round-robin; per stream the time from
+// its first to its last launch.  On this runtime three streams always do; a fourth may land on a hardware queue that is time-sliced
+// with another stream's on one pipe -- whether it does differs from box to box and run to run (profiles/r04_stream_probe*.txt,
+// r04_batched_pipeline_again.txt) -- and then every small launch on the two sharing streams takes 40-70 us instead of 11.
+// worst_us: the slowest stream's time per launch.  Costs reps x 10 us.
+int streams_abreast(hipStream_t* st, int n, int reps, double* worst_us, double* best_us) {
+  std::vector<hipEvent_t> e0(n), e1(n);
+  for (int i = 0; i < n; ++i) { GPK_HIP(hipEventCreate(&e0[i])); GPK_HIP(hipEventCreate(&e1[i])); }
+  for (int i = 0; i < n; ++i) GPK_TRY(launch_spin(100, st[i]));  // the queues exist
+  for (int i = 0; i < n; ++i) GPK_HIP(hipStreamSynchronize(st[i]));
+  for (int i = 0; i < n; ++i) GPK_HIP(hipEventRecord(e0[i], st[i]));
+  for (int r = 0; r < reps; ++r)
+    for (int i = 0; i < n; ++i) GPK_TRY(launch_spin(1000, st[i]));
+  for (int i = 0; i < n; ++i) GPK_HIP(hipEventRecord(e1[i], st[i]));
+  for (int i = 0; i < n; ++i) GPK_HIP(hipStreamSynchronize(st[i]));
+  double worst = 0.0, best = 1e30;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0;
+    GPK_HIP(hipEventElapsedTime(&ms, e0[i], e1[i]));
+    worst = std::max(worst, 1e3 * ms / reps);
+    best = std::min(best, 1e3 * ms / reps);
+    (void)hipEventDestroy(e0[i]);
+    (void)hipEventDestroy(e1[i]);
+  }
+  *worst_us = worst;
+  if (best_us) *best_us = best;
+  return 0;
+}
+static constexpr double GPK_ABREAST_MAX_US = 16.0;
+int g_dist_streams_abreast = -1;   // what gpk_comm_init's probe of the four-stream layout found: 1 abreast, 0 time-sliced (substitution stream given up), -1 not probed
+double g_dist_streams_worst_us = 0.0;
+
+extern "C" {
+
 int gpk_comm_init(int rank, int nranks, const void* uid128) {
   GPK_TRY(rt_require());
   if (G.nccl) return gpk_set_err(-1, "gpk_comm_init: communicator already initialised");
@@ -75,6 +111,25 @@ int gpk_comm_init(int rank, int nranks, const void* uid128) {
     // comm_stream() in gpk_core.hip) rather than leave the process half initialised
     (void)hipGetLastError();
     G.s_comm = nullptr;
+  }
+  // dist_pipeline = 1 (default): keep the four-stream layout only if the four DO run abreast in this process on this GPU -- a
+  // time-sliced pair costs every small launch of the chain 4x (N = 4096 one-GPU with a fourth stream: 2.85 -> 6.9-9.0 ms on a box
+  // that draws the short straw); else the three-stream layout of dist_pipeline = 0.  dist_pipeline = 2: four streams, no probe.
+  g_dist_streams_abreast = -1;
+  if (G.dist_pipeline == 1 && G.s_comm && G.s_pred && G.s_pred != G.s_panel) {
+    hipStream_t st[4] = {G.s_main, G.s_panel, G.s_pred, G.s_comm};
+    double worst = 0.0, best = 0.0;
+    if (streams_abreast(st, 4, 40, &worst, &best) == 0) {
+      g_dist_streams_worst_us = worst;
+      g_dist_streams_abreast = (worst <= GPK_ABREAST_MAX_US) ? 1 : 0;  // (the launches spin for exactly 10 us; 11-12 abreast, 19-70 time-sliced)
+      if (!g_dist_streams_abreast) {
+        (void)hipStreamSynchronize(G.s_pred);
+        (void)hipStreamDestroy(G.s_pred);
+        G.s_pred = nullptr;
+      }
+    } else {
+      (void)hipGetLastError();
+    }
   }
   return 0;
 }

@@ -49,7 +49,8 @@ struct Runtime {
   int dist_tail_alone = -1; // the tail's owner keeps out of the cyclic part (gpk_model::Pc): -1 where the work model says so, 0 never, 1 whenever P >= 3
   int dist_tail_chunk = 8; // ... whose panels are broadcast this many at a time
   int dist_pipeline = 1;  // multi-rank process: keep the substitution stream next to the communication stream and pipeline y / this rank's
-                          // shard of the prediction behind the per-panel "available" events (fit_group_impl); 0: three streams, prediction afterwards
+                          // shard of the prediction behind the per-panel "available" events (fit_group_impl) -- if gpk_comm_init's probe finds the four
+                          // streams running abreast (streams_abreast); 0: three streams, prediction afterwards; 2: four streams without the probe
   // tile pipeline (potrf_tail) for the chain-bound last tail_rows columns (needs 128-wide panels there: nb_small_from);
   // 0 = the panel-level look-ahead everywhere
   int tail_rows = 4096;
@@ -268,6 +269,9 @@ int predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* 
 // fit + sharded prediction in one go: the y and prediction substitutions pipelined behind the per-panel events of the block-cyclic factorisation
 int fit_predict_group(gpk_model* const* ms, int n, const double* dZ, int M, double* const* h_mean, double* const* h_var);
 extern int g_dist_tail_from;        // first panel the last block-cyclic factorisation ran through the tile pipeline on the tail's owner (-1: none)
+extern int g_dist_streams_abreast;  // gpk_comm_init's probe of the four-stream layout: 1 abreast, 0 time-sliced (three streams kept), -1 not probed
+extern double g_dist_streams_worst_us;
+int streams_abreast(hipStream_t* st, int n, int reps, double* worst_us, double* best_us);  // gpk_comm.hip
 extern int g_potrf_tail_stream;     // 1 if the last tile pipeline used the near stream
 extern int g_kbuild_split;          // 1 if the last fused fit built K in two launches (first block column, rest)
 extern int g_dist_tail_owner;       // ... its owner; P + owner if that rank keeps out of the cyclic part

@@ -594,7 +594,6 @@ static int potrf_tail(gpk_model* m, int p_first, hipEvent_t ev_prev_rest, const 
     GPK_HIP(hipStreamWaitEvent(sn, ev_in, 0));
   }
   g_potrf_tail_stream = sn != sm ? 1 : 0;
-  const bool near_on = sn != sm;
   const unsigned epoch = ++G.flag_epoch;
   g_potrf_chain_fused = 0;
   for (int p = p_first; p < nP; ++p) {

@@ -361,6 +361,24 @@ int gpk_bench_streams(int nstreams, int high_mask, int low_mask, int wgs, int us
   return 0;
 }
 
+// the product's stream-layout probe (streams_abreast, gpk_comm.hip: what gpk_comm_init runs on its four streams) on the library's three
+// streams plus n_high high-priority and n_normal normal-priority ones created here; out2 = worst, best time per launch in us
+int gpk_test_streams_abreast(int n_high, int n_normal, int reps, double* out2) {
+  GPK_TRY(rt_require());
+  if (n_high < 0 || n_normal < 0 || n_high + n_normal > 5 || reps < 1) return gpk_set_err(-1, "gpk_test_streams_abreast: bad arguments");
+  int lo = 0, hi = 0;
+  GPK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  std::vector<hipStream_t> st = {G.s_main, G.s_panel, G.s_pred};
+  for (int i = 0; i < n_high + n_normal; ++i) {
+    hipStream_t x = nullptr;
+    GPK_HIP(hipStreamCreateWithPriority(&x, hipStreamNonBlocking, i < n_high ? hi : (lo + hi) / 2));
+    st.push_back(x);
+  }
+  const int rc = streams_abreast(st.data(), (int)st.size(), reps, out2, out2 + 1);
+  for (size_t i = 3; i < st.size(); ++i) (void)hipStreamDestroy(st[i]);
+  return rc;
+}
+
 int gpk_bench_lds_bank_probe(int pattern, int reps) {
   GPK_TRY(rt_require());
   Scratch sc;

@@ -160,6 +160,7 @@ int launch_diag_solve(const double* Lp, int w, long ld, const double* Dinv, doub
 int launch_transpose(const double* in, long ldin, int rows, int cols, double* out, long ldout, hipStream_t s);
 int launch_fill(double* p, size_t n, double v, hipStream_t s);
 int launch_stamp(unsigned long long* out, hipStream_t s);
+int launch_spin(unsigned long long ticks, hipStream_t s);  // one wave spinning for `ticks` of the 100 MHz clock (stream-layout probe)
 int launch_set_diag(double* p, long ld, int n, double v, hipStream_t s);
 int launch_unpack_L(const double* Lp, int w, long ld, int h, int c0, double* out, long ldout, hipStream_t s);
 int launch_gather2d(const double* K, long ldk, const long long* idx, int nidx, double* out, hipStream_t s);

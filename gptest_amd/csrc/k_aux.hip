@@ -471,3 +471,14 @@ int launch_stamp(unsigned long long* out, hipStream_t s) {
   GPK_HIP(hipGetLastError());
   return 0;
 }
+
+// one wave that waits `ticks` of the constant 100 MHz clock: the unit of the stream-layout probe (streams_abreast, gpk_comm.hip)
+__global__ void spin_ticks_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+int launch_spin(unsigned long long ticks, hipStream_t s) {
+  hipLaunchKernelGGL(spin_ticks_kernel, dim3(1), dim3(64), 0, s, ticks);
+  GPK_HIP(hipGetLastError());
+  return 0;
+}

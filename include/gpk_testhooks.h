@@ -49,6 +49,9 @@ int gpk_bench_gemm_nt(int m, int n, int k, int lower, int tile, int reps, double
  * library's own update / chain / substitution streams), `reps` small spinning launches (wgs workgroups, us_each microseconds) on each,
  * queued round robin.  out_us[i] = time per launch on stream i, out_us[nstreams] = host wall time per round. */
 int gpk_bench_streams(int nstreams, int high_mask, int low_mask, int wgs, int us_each, int reps, int use_lib_streams, double* out_us);
+/* streams_abreast (the probe gpk_comm_init runs on a multi-rank process's four streams) on the library's three streams plus n_high
+   high-priority and n_normal normal-priority ones; out2 = {worst, best} microseconds per 10 us launch */
+int gpk_test_streams_abreast(int n_high, int n_normal, int reps, double* out2);
 /* One rank of a P-rank block-cyclic posterior ALONE on the GPU (P virtual ranks in this process; the whole job runs once, then
  * each rank's share is replayed by itself `reps` times, panels of other owners arriving as device copies, never late):
  * ms_out[r] = the best time of rank r, r < P -- a lower bound of the P-GPU job's time, max over r.  comm_stream != 0: those copies

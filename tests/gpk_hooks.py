@@ -32,6 +32,7 @@ def _bind(l):
         "gpk_bench_gemm_nt": (i, [i, i, i, i, i, i, dp]),
         "gpk_bench_lds_bank_probe": (i, [i, i]),
         "gpk_bench_streams": (i, [i, i, i, i, i, i, i, dp]),
+        "gpk_test_streams_abreast": (i, [i, i, i, dp]),
         "gpk_bench_leaf": (i, [i, i, dp]),
         "gpk_bench_leaf_contended": (i, [i, dp, dp]),
         "gpk_bench_chain_step": (i, [i, i, i, dp, dp]),

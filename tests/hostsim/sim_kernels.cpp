@@ -320,6 +320,7 @@ int launch_transpose(const double* in, long ldin, int rows, int cols, double* ou
 }
 int launch_fill(double* p, size_t n, double v, hipStream_t) { std::fill(p, p + n, v); return 0; }
 int launch_stamp(unsigned long long* out, hipStream_t) { *out = 1; return 0; }
+int launch_spin(unsigned long long, hipStream_t) { return 0; }
 int launch_set_diag(double* p, long ld, int n, double v, hipStream_t) {
   for (int i = 0; i < n; ++i) p[(long)i * ld + i] = v;
   return 0;

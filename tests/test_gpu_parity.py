@@ -1712,6 +1712,23 @@ def test_rccl_calls_on_a_one_rank_communicator(gpk):
     assert hooks().gpk_test_rccl_selfcheck(16384 * 256) == 0, gpk.last_error()
 
 
+def test_stream_layout_probe_tells_abreast_from_time_sliced(gpk):
+    """gpk_comm_init keeps the substitution stream next to the communication stream only if its probe (streams_abreast) finds the
+    four streams running abreast; a time-sliced pair takes 40-70 us per 10 us launch (profiles/r04_stream_probe.txt).  Here the
+    same probe on the library's own three streams (always abreast on this runtime) and on seven (never: three more than fit)."""
+    out = np.zeros(2)
+    assert hooks().gpk_test_streams_abreast(0, 0, 40, _ptr(out)) == 0, gpk.last_error()
+    worst3, best3 = out
+    assert 9.0 < best3 <= worst3 <= 16.0, (worst3, best3)   # (16 us: the threshold gpk_comm_init applies to launches that spin for 10 us)
+    assert hooks().gpk_test_streams_abreast(2, 2, 40, _ptr(out)) == 0, gpk.last_error()
+    worst7, best7 = out
+    assert worst7 > 16.0, (worst7, best7)
+    # the four-stream layout of a multi-rank process: either answer is legitimate, it differs from box to box -- the probe's point
+    assert hooks().gpk_test_streams_abreast(1, 0, 40, _ptr(out)) == 0, gpk.last_error()
+    print("three library streams + one high-priority stream: worst %.1f us, best %.1f us per launch -> %s"
+          % (out[0], out[1], "abreast" if out[0] <= 16.0 else "time-sliced"))
+
+
 # ----------------------------------------------------------------------------- API edges
 def test_api_rejects_empty_and_malformed_calls(gpk):
     """Empty / out-of-range arguments come back as negative return codes with a message (never a fault); ragged test
