@@ -182,9 +182,6 @@ int gpk_set_option(const char* key, double value) {
     G.small_tile_below = v;
   } else if (k == "tail_tile_kernel") {
     G.tail_tile_kernel = v < 0 ? -1 : (v ? 1 : 0);
-  } else if (k == "pred_defer_early") {
-    if (v < 0 || v % 128) return gpk_set_err(-1, "option pred_defer_early=%d must be 0 (off) or a positive multiple of 128", v);
-    G.pred_defer_early = v;
   } else if (k == "pred_defer_from") {
     if (v < -1 || (v > 0 && v % 128)) return gpk_set_err(-1, "option pred_defer_from=%d must be -1 (automatic), 0 (off) or a positive multiple of 128", v);
     G.pred_defer_from = v;
@@ -252,7 +249,6 @@ double gpk_get_option(const char* key) {
   if (k == "flags_ok") return G.flags_ok;
   if (k == "potrf_chain_fused") { extern int g_potrf_chain_fused; return g_potrf_chain_fused; }
   if (k == "pred_defer_from") return G.pred_defer_from;
-  if (k == "pred_defer_early") return G.pred_defer_early;
   if (k == "tail_tile_kernel") return G.tail_tile_kernel;
   if (k == "corner_from") return G.corner_from;
   if (k == "corner_chunk") return G.corner_chunk;
@@ -285,7 +281,6 @@ double gpk_get_option(const char* key) {
       return c0 ? g_last_pc0[p] : g_last_pw[p];
     }
     if (k == "pred_defer_col") { extern int g_pred_defer_col; return g_pred_defer_col; }
-    if (k == "pred_defer_early_col") { extern int g_pred_defer_early; return g_pred_defer_early; }
   }
   // diagnostic stamps of the last fused fit: "stamp_panel_<p>" / "stamp_subst_<p>" in ms after panel 0
   if (k.rfind("stamp_", 0) == 0 && G.hstamps.size() == 1024 && G.hstamps[0]) {

@@ -58,7 +58,6 @@ struct Runtime {
   int pair_update = 1;    // two panels per trailing update (K doubled) for the far region: 0 never, 1 for Npad <= 8192, 2 always
   int fuse_predict = 1;   // bench / compute_prediction: overlap the prediction solve with the factorisation tail
   int tail_tile_kernel = -1; // (-1: automatic, for Npad < 12288) tile pipeline: the two one-tile GEMMs of a step on the LDS-free 64-wave kernel instead of the 64x64-tile one
-  int pred_defer_early = 0;  // pred_defer: the deferred updates of the panels in front of this column are queued when the substitution reaches IT, the rest at the boundary (0: all at the boundary)
   int pred_defer_from = -1;  // (-1: automatic, 5/8 of the columns from Npad = 12288 on; 0: off) pipelined prediction: panels that end at or before this column update only the columns below it right away; their updates of the columns from it on are queued, in panel order, when the substitution reaches it (0: off)
   // Lazy corner (potrf_device, one GPU, one-level schedule): with b the first panel boundary at or after corner_from, a panel that
   // ends before b applies its trailing update right away only to the trapezoid of columns < b; the corner [b:, b:] receives the

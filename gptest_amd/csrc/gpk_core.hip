@@ -1683,8 +1683,6 @@ static int predict_outer_update(gpk_model* m, int o, int Mpad, int cg0, int ncol
 // 33.9; several boundaries instead of one were measured and lose: the later ones run into the end of the factorisation).
 struct PredDefer {
   int b = 0;  // the boundary column
-  int a = 0;  // option pred_defer_early: the deferred updates of the outer panels that end at or before column a are queued when the
-              // substitution reaches a (0: all of them at b) -- the same launches in the same order, part of them earlier
 };
 static int predict_defer_col(const gpk_model* m) {
   int want = G.pred_defer_from;
@@ -1697,11 +1695,8 @@ static int predict_defer_col(const gpk_model* m) {
 static int predict_step(gpk_model* m, int p, int Mpad, double* dR, double* dV, hipStream_t s, const PredDefer* df = nullptr) {
   const int o = m->pouter[p];
   const int cend = m->oc0[o] + m->ow[o], c1 = m->pc0[p] + m->pw[p];
-  if (df && df->a > 0 && p == m->ofirst[o] && m->oc0[o] == df->a)
-    for (int q = 0; q < o; ++q) GPK_TRY(predict_outer_update(m, q, Mpad, df->b, m->Npad - df->b, dR, dV, s));
   if (df && p == m->ofirst[o] && m->oc0[o] == df->b)
-    for (int q = 0; q < o; ++q)
-      if (!(df->a > 0 && m->oc0[q] + m->ow[q] <= df->a)) GPK_TRY(predict_outer_update(m, q, Mpad, df->b, m->Npad - df->b, dR, dV, s));
+    for (int q = 0; q < o; ++q) GPK_TRY(predict_outer_update(m, q, Mpad, df->b, m->Npad - df->b, dR, dV, s));
   GPK_TRY(predict_diag(m, p, Mpad, dR, dV, s));
   GPK_TRY(predict_update(m, p, Mpad, c1, cend - c1, dR, dV, s));
   if (p == m->oend[o] - 1) {
@@ -1712,17 +1707,12 @@ static int predict_step(gpk_model* m, int p, int Mpad, double* dR, double* dV, h
 }
 
 int g_pred_defer_col = 0;  // boundary the last fused prediction deferred its far updates to (0: none)
-int g_pred_defer_early = 0;  // ... and the column at which the first part of them was queued (0: all at the boundary)
 static std::shared_ptr<PredDefer> predict_defer_make(const gpk_model* m) {
   const int b = predict_defer_col(m);
   g_pred_defer_col = b > 0 ? b : 0;
   if (b <= 0) return nullptr;
   auto d = std::make_shared<PredDefer>();
   d->b = b;
-  g_pred_defer_early = 0;
-  if (G.pred_defer_early > 0)
-    for (int o = 1; o < m->nO; ++o)
-      if (m->oc0[o] >= G.pred_defer_early) { if (m->oc0[o] < b) d->a = g_pred_defer_early = m->oc0[o]; break; }
   return d;
 }
 

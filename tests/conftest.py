@@ -30,7 +30,7 @@ def golden_cases():
 
 # every option gpk_set_option knows (schedule switches, the launch-graph switch, the two diagnostics)
 OPTION_KEYS = ["nb", "nb_big_until", "nb_small_from", "nb_outer", "outer_until", "lookahead", "dist_group", "dist_pipeline", "dist_tail", "dist_tail_chunk", "dist_tail_alone", "se_scalar", "kbuild_split", "tail_stream", "tail_rows",
-               "leaf_fat_rows", "gemm_polite", "pair_update", "fuse_predict", "small_tile_below", "pred_defer_from", "pred_defer_early", "tail_tile_kernel", "chain_fused",
+               "leaf_fat_rows", "gemm_polite", "pair_update", "fuse_predict", "small_tile_below", "pred_defer_from", "tail_tile_kernel", "chain_fused",
                "corner_from", "corner_from2", "corner_from3", "corner_chunk", "corner_last", "corner_prio", "corner_hold", "corner_grid", "stamps", "timing"]
 
 

@@ -61,9 +61,6 @@ int main() {
   // far-column updates of the pipelined prediction deferred to a boundary (default schedule, two boundaries; and two-level below)
   opt("pred_defer_from", 512); check_fit_predict(make_problem(1500, 3, 40), "deferred far updates from column 512");
   opt("pred_defer_from", 1152); check_fit_predict(make_problem(1500, 3, 40), "deferred far updates from column 1152 (the next panel start is taken)");
-  opt("pred_defer_early", 512); check_fit_predict(make_problem(1500, 3, 40), "deferred far updates from column 1152, the first part of them at column 512");
-  CHECK(gpk_get_option("pred_defer_early_col") == 512, "early part of the deferred updates at column 512: %g", gpk_get_option("pred_defer_early_col"));
-  opt("pred_defer_early", 0);
   // two-level blocking forced onto small problems (active from Npad >= 3 * outer_until)
   opt("nb_outer", 1024); opt("outer_until", 256); opt("nb_big_until", 512); opt("nb_small_from", 256); opt("tail_rows", 0);
   opt("pred_defer_from", 1024);

@@ -527,14 +527,6 @@ def test_deferred_far_updates_of_the_prediction_are_bitwise_the_immediate_ones(g
         gpk.set_option("pred_defer_from", c)
         n1, m1, v1 = posterior()
         assert n1 == n0 and np.array_equal(m1, m0) and np.array_equal(v1, v0), c
-    # ... and with the first part of the deferred updates queued at an earlier column (option pred_defer_early)
-    gpk.set_option("pred_defer_from", cols[-1])
-    for a in cols[:-1]:
-        gpk.set_option("pred_defer_early", a)
-        n1, m1, v1 = posterior()
-        assert gpk.get_option("pred_defer_early_col") in (0, a), a
-        assert n1 == n0 and np.array_equal(m1, m0) and np.array_equal(v1, v0), a
-    gpk.set_option("pred_defer_early", 0)
     nl_o, fz_o, cov_o = orc.posterior_efficient(lh, X, y, Z)
     np.testing.assert_allclose(m0, fz_o, rtol=RTOL, atol=RTOL * np.abs(fz_o).max())
     np.testing.assert_allclose(v0, cov_o, rtol=RTOL, atol=RTOL * np.abs(cov_o).max())
