@@ -3,6 +3,8 @@
 // Laplace / append drivers) runs under AddressSanitizer + UBSan without a GPU.  Each stand-in touches exactly the
 // memory the HIP kernel touches (same tiles, same padding rules), so a wrong size or offset computed by the host code
 // is a sanitizer report here instead of a fault on the device.  Nothing in gptest_amd/ or bench.py can reach this file.
+#include <unistd.h>
+#include <cstdlib>
 #include "gpk_internal.h"
 #include <algorithm>
 #include <cmath>
@@ -320,7 +322,10 @@ int launch_transpose(const double* in, long ldin, int rows, int cols, double* ou
 }
 int launch_fill(double* p, size_t n, double v, hipStream_t) { std::fill(p, p + n, v); return 0; }
 int launch_stamp(unsigned long long* out, hipStream_t) { *out = 1; return 0; }
-int launch_spin(unsigned long long, hipStream_t) { return 0; }
+int launch_spin(unsigned long long, hipStream_t) {  // HOSTSIM_SPIN_US: every spin takes that long, so the stream-layout probe sees "time-sliced"
+  if (const char* e = std::getenv("HOSTSIM_SPIN_US")) usleep((useconds_t)std::atoi(e));
+  return 0;
+}
 int launch_set_diag(double* p, long ld, int n, double v, hipStream_t) {
   for (int i = 0; i < n; ++i) p[(long)i * ld + i] = v;
   return 0;

@@ -21,11 +21,19 @@ struct Shipped {  // what a rank reports: scenario A (three ways), the not-posit
   int fails;
 };
 
-static int rank_main(int rank, int P, const unsigned char* uid, int out_fd) {
+// layout: 0 = what gpk_comm_init decides (its stream-layout probe sees the stand-in streams abreast: four streams), 1 = option
+// dist_pipeline = 0 (three streams), 2 = the probe sees a time-sliced pair (HOSTSIM_SPIN_US: the stand-in spin takes that long) and
+// gives up the substitution stream -- the fallback a real node may take on some boxes and not on others
+static int rank_main(int rank, int P, const unsigned char* uid, int out_fd, int layout) {
   Shipped sh{};
   CHECK(gpk_init(0) == 0, "init");
+  if (layout == 1) opt("dist_pipeline", 0);
+  if (layout == 2) setenv("HOSTSIM_SPIN_US", "40", 1);
   CHECK(gpk_comm_init(rank, P, uid) == 0, "comm init rank %d of %d", rank, P);
+  unsetenv("HOSTSIM_SPIN_US");
   CHECK(gpk_comm_rank() == rank && gpk_comm_size() == P, "rank / size");
+  if (P > 1) CHECK(gpk_get_option("dist_streams_abreast") == (layout == 0 ? 1 : layout == 1 ? -1 : 0), "stream-layout probe (layout %d): %g, worst %g us",
+                   layout, gpk_get_option("dist_streams_abreast"), gpk_get_option("dist_streams_worst_us"));
   const Problem p = make_problem(900, 3, 70);
   const Posterior ref = dense_posterior(p, p.N);
   auto close_to_ref = [&](double nl, const vec& m, const vec& v, const char* what) {
@@ -124,7 +132,7 @@ static int rank_main(int rank, int P, const unsigned char* uid, int out_fd) {
 }
 
 // One job of P ranks; results of rank 0 in *first.  Returns false on any failure.
-static bool run_job(int P, Shipped* first, double limit_s) {
+static bool run_job(int P, Shipped* first, double limit_s, int layout = 0) {
   unsigned char uid[GPK_UNIQUE_ID_BYTES];
   if (gpk_comm_unique_id(uid) != 0) { std::fprintf(stderr, "unique id: %s\n", gpk_last_error()); return false; }
   std::vector<pid_t> pid(P);
@@ -137,7 +145,7 @@ static bool run_job(int P, Shipped* first, double limit_s) {
     if (pid[r] == 0) {
       close(fd[0]);
       for (int q = 0; q < r; ++q) close(rd[q]);
-      _exit(rank_main(r, P, uid, fd[1]));
+      _exit(rank_main(r, P, uid, fd[1], layout));
     }
     close(fd[1]);
     rd[r] = fd[0];
@@ -194,6 +202,16 @@ int main() {
     if (!(worst <= 1e-10)) { std::fprintf(stderr, "%d ranks against one process: %g\n", P, worst); ok = false; }
     if (many.rc_notpd != one.rc_notpd) { std::fprintf(stderr, "%d ranks report minor %d, one process %d\n", P, many.rc_notpd, one.rc_notpd); ok = false; }
     std::printf("hostsim ranks: %d processes agree bit for bit with each other and to %.1e with the one-process job\n", P, worst);
+    // the three-stream layouts (by option; by the probe's verdict): the same operations in the same order -> the four-stream job's bits
+    for (int layout : {1, 2}) {
+      if (P == 4 && layout == 1) continue;
+      Shipped alt{};
+      if (!run_job(P, &alt, 600.0, layout)) { ok = false; continue; }
+      Shipped a = many, b = alt;
+      a.fails = b.fails = 0;
+      if (std::memcmp(&a, &b, sizeof a) != 0) { std::fprintf(stderr, "%d ranks, stream layout %d: results differ from the four-stream job\n", P, layout); ok = false; }
+      else std::printf("hostsim ranks: %d processes, %s: bit for bit the four-stream job\n", P, layout == 1 ? "dist_pipeline = 0" : "substitution stream given up after the probe");
+    }
   }
   {
     // a rank that never shows up: the others must come back with an error from gpk_comm_init, not hang
