@@ -171,7 +171,7 @@ int gpk_set_option(const char* key, double value) {
     G.leaf_fat_rows = v;
   } else if (k == "gemm_polite") {
     extern int g_gemm_polite;
-    g_gemm_polite = v < 0 ? 0 : (v > 2 ? 2 : (int)v);
+    g_gemm_polite = v ? 1 : 0;
   } else if (k == "pair_update") {
     G.pair_update = v;
   } else if (k == "fuse_predict") {

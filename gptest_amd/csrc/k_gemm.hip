@@ -214,19 +214,7 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
 template <int WT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
   __shared__ double lds[2 * 2 * (2 * WT * 16) * LDS_LD];
-  // option gemm_polite = 2: a launch on the panel-chain stream announces itself in the guest table like the leaf (g.prio == 2, and it
-  // does not poll: g.guest is the table to ANNOUNCE in), so that the bulk update's workgroups on its CUs pause while it runs
-  unsigned* gslot = nullptr;
-  if (g.prio == 2 && g.guest && threadIdx.x == 0) {
-    gslot = const_cast<unsigned*>(g.guest) + cu_guest_slot();
-    __hip_atomic_fetch_add(gslot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (g.prio == 2) g.guest = nullptr;
   gemm_nt_body<WT>(g, (int)blockIdx.x, lds);
-  if (gslot) {
-    __builtin_amdgcn_s_waitcnt(0);
-    __hip_atomic_fetch_sub(gslot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -647,8 +635,7 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
   }
   if (!tile128) {
     GemmNT h = g;
-    h.prio = (s == g_chain_stream) ? ((g_gemm_polite == 2 && g_cu_guest && !g.wait_flag) ? 2 : 1) : 0;
-    if (h.prio == 2) h.guest = g_cu_guest;
+    h.prio = (s == g_chain_stream) ? 1 : 0;
     hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, h);
     GPK_HIP(hipGetLastError());
     return 0;
