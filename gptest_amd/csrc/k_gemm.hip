@@ -41,7 +41,7 @@ static __device__ __forceinline__ unsigned cu_guest_slot() {
 }
 
 // One block tile of the 4-wave kernel (block `bid` of the launch described by g); lds: 2 * 2 * BT * LDS_LD doubles.
-template <int WT>  // MFMA tiles per wave per dimension: 2 -> 64x64 block
+template <int WT, int NS>  // WT: MFMA tiles per wave per dimension (2 -> 64x64 block); NS: register stage sets = slabs in flight
 static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int bid, double* lds) {
   constexpr int BT = 2 * WT * 16;       // block tile edge
   constexpr int PASSES = BT / 32;       // 32 rows of 16 doubles per pass with 256 threads
@@ -110,28 +110,32 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
   // ---- global -> register staging: 16-byte chunks, 8 chunks per 128-byte row segment
   const int lrow = tid >> 3;        // 0..31
   const int lchk = (tid & 7) * 2;   // double offset inside the BK row
-  d2 ra[PASSES], rb[PASSES];
-  auto gload = [&](int kt) {
+  // NS slabs in flight (register set = slab index mod NS)
+  d2 ra[NS][PASSES], rb[NS][PASSES];
+  auto gload = [&](int kt, auto setc) {
+    constexpr int S = decltype(setc)::value;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const double* pa_ = Ag + (long)(p * 32 + lrow) * g.lda + kt * BK + lchk;
       const double* pb_ = Bg + (long)(p * 32 + lrow) * g.ldb + kt * BK + lchk;
-      ra[p] = *reinterpret_cast<const d2*>(pa_);
-      rb[p] = *reinterpret_cast<const d2*>(pb_);
+      ra[S][p] = *reinterpret_cast<const d2*>(pa_);
+      rb[S][p] = *reinterpret_cast<const d2*>(pb_);
     }
   };
   // sub mode, exactly as in the 8-wave kernel below (so that every kernel of this file rounds identically and the
   // choice of tile size never changes a bit of the factor): accumulators start as C, A is negated on its way
   // into LDS, the epilogue only stores.
   const double sgn = g.sub ? -1.0 : 1.0;
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, auto setc) {
+    constexpr int S = decltype(setc)::value;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      d2 na = {sgn * ra[p].x, sgn * ra[p].y};
+      d2 na = {sgn * ra[S][p].x, sgn * ra[S][p].y};
       *reinterpret_cast<d2*>(As + (buf * BT + p * 32 + lrow) * LD + lchk) = na;
-      *reinterpret_cast<d2*>(Bs + (buf * BT + p * 32 + lrow) * LD + lchk) = rb[p];
+      *reinterpret_cast<d2*>(Bs + (buf * BT + p * 32 + lrow) * LD + lchk) = rb[S][p];
     }
   };
+  using set0 = std::integral_constant<int, 0>;
 
   const int nk = g.k / BK;
   const int fr = lane & 15, fg = lane >> 4;
@@ -148,16 +152,27 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
         acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
       }
     }
-  gload(0);
-  lstore(0);
+  gload(0, set0{});
+  if constexpr (NS > 1) { if (nk > 1) gload(1, std::integral_constant<int, 1 % NS>{}); }
+  if constexpr (NS > 2) { if (nk > 2) gload(2, std::integral_constant<int, 2 % NS>{}); }
+  if constexpr (NS > 3) { if (nk > 3) gload(3, std::integral_constant<int, 3 % NS>{}); }
+  if constexpr (NS > 4) {
+    if (nk > 4) gload(4, std::integral_constant<int, 4 % NS>{});
+    if (nk > 5) gload(5, std::integral_constant<int, 5 % NS>{});
+    if (nk > 6) gload(6, std::integral_constant<int, 6 % NS>{});
+    if (nk > 7) gload(7, std::integral_constant<int, 7 % NS>{});
+  }
+  lstore(0, set0{});
   __syncthreads();
   // guest poll (gpk_internal.h), as in the 8-wave kernel: wave 0 reads its CU's counter with the slab's loads
   const unsigned* gslot = (wid == 0 && g.guest) ? g.guest + cu_guest_slot() : nullptr;
-  for (int kt = 0; kt < nk; ++kt) {
+  unsigned gv = 0;
+  auto slab = [&](int kt, auto setc) {  // setc: kt mod NS = the register set of slabs kt and kt + NS
+    constexpr int S = decltype(setc)::value;
+    using same = std::integral_constant<int, S>;
+    using next = std::integral_constant<int, (S + 1) % NS>;
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    unsigned gv = 0;
-    if (gslot) gv = __hip_atomic_load(gslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (kt + NS < nk) gload(kt + NS, same{});  // (set S is free: slab kt went to LDS an iteration ago)
     const double* Ab = As + (buf * BT + wm * WT * 16 + fr) * LD + fg;
     const double* Bb = Bs + (buf * BT + wn * WT * 16 + fr) * LD + fg;
     {
@@ -185,15 +200,33 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
-    if (gslot && __builtin_amdgcn_readfirstlane((int)gv) != 0) {  // a guest is on this CU: the other waves stop at the barrier
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      do {
-        __builtin_amdgcn_s_sleep(32);
-        gv = __hip_atomic_load(gslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } while (__builtin_amdgcn_readfirstlane((int)gv) != 0 && __builtin_amdgcn_s_memrealtime() - t0 < GPK_GUEST_LIMIT_TICKS);
+    if (kt + 1 < nk) lstore(buf ^ 1, next{});
+    if (gslot) {  // wave 0.  The value looked at was requested a slab ago -- behind slab kt + NS - 1, in front of slab kt + NS: it has had a
+                  // whole iteration to land, and waiting for it waits for nothing this iteration would not have needed anyway (NS >= 2).
+                  // Read and looked at within one iteration (the form before) every slab cost wave 0, hence the workgroup, a full
+                  // round trip of an L2-coherent load: N = 8192 -2.5 %, N = 4096 -3.6 %, N = 16384 -1.3 % for moving it alone.
+      if (__builtin_amdgcn_readfirstlane((int)gv) != 0) {  // a guest is on this CU: the other waves stop at the barrier
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        do {
+          __builtin_amdgcn_s_sleep(32);
+          gv = __hip_atomic_load(gslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (__builtin_amdgcn_readfirstlane((int)gv) != 0 && __builtin_amdgcn_s_memrealtime() - t0 < GPK_GUEST_LIMIT_TICKS);
+      }
+      gv = __hip_atomic_load(gslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += NS) {
+    slab(kt, set0{});
+    if constexpr (NS > 1) { if (kt + 1 < nk) slab(kt + 1, std::integral_constant<int, 1 % NS>{}); }
+    if constexpr (NS > 2) { if (kt + 2 < nk) slab(kt + 2, std::integral_constant<int, 2 % NS>{}); }
+    if constexpr (NS > 3) { if (kt + 3 < nk) slab(kt + 3, std::integral_constant<int, 3 % NS>{}); }
+    if constexpr (NS > 4) {
+      if (kt + 4 < nk) slab(kt + 4, std::integral_constant<int, 4 % NS>{});
+      if (kt + 5 < nk) slab(kt + 5, std::integral_constant<int, 5 % NS>{});
+      if (kt + 6 < nk) slab(kt + 6, std::integral_constant<int, 6 % NS>{});
+      if (kt + 7 < nk) slab(kt + 7, std::integral_constant<int, 7 % NS>{});
+    }
   }
 
   // ---- epilogue: C/D layout col = lane&15, row = (lane>>4) + 4*reg
@@ -211,10 +244,10 @@ static __device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int b
 }
 
 
-template <int WT>
+template <int WT, int NS>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
   __shared__ double lds[2 * 2 * (2 * WT * 16) * LDS_LD];
-  gemm_nt_body<WT>(g, (int)blockIdx.x, lds);
+  gemm_nt_body<WT, NS>(g, (int)blockIdx.x, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -636,7 +669,9 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
   if (!tile128) {
     GemmNT h = g;
     h.prio = (s == g_chain_stream) ? 1 : 0;
-    hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, h);
+    // two slabs in flight (one, three, four, eight measured the same once the guest poll was out of the slab's dependent path:
+    // profiles/r04_skinny_gemm_poll.txt)
+    hipLaunchKernelGGL((gemm_nt_kernel<2, 2>), dim3((unsigned)nblk), dim3(256), 0, s, h);
     GPK_HIP(hipGetLastError());
     return 0;
   }
