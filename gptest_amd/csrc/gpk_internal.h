@@ -62,6 +62,7 @@ struct GemmNT {
   const double* B2; long ldb2;
   int k1;
   const unsigned* guest;  // the guest table (filled in by launch_gemm_nt; nullptr = do not poll)
+  int poll_mask;  // 8-wave kernel: the guest counter is requested in the slabs kt with (kt & poll_mask) == poll_mask (0: every slab)
   int prio;  // 64x64-tile kernel: raise the waves' issue priority (s_setprio): set by launch_gemm_nt for launches on the panel-chain stream
   unsigned long long* trace;  // timing builds only (make DBG=1): per-workgroup time stamps
   // 64x64-tile kernel: every workgroup waits (bounded; a time-out poisons *wait_info) until *wait_flag has reached wait_val before

@@ -558,7 +558,7 @@ static __device__ __forceinline__ void gemm_nt8_tile(const GemmNT& g, const type
     mm(1);
     __builtin_amdgcn_sched_barrier(0);
     if (!(DBG & 1) && kt + 2 < nk) dma(buf);
-    if (gslot) {  // scalar branch: wave 0
+    if (gslot && (kt & g.poll_mask) == g.poll_mask) {  // scalar branch: wave 0
       if (__builtin_amdgcn_readfirstlane((int)gv) != 0) {
         // a guest (the leaf) is on this CU: stay out of its way.  The other seven waves stop at the next barrier.
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -656,6 +656,7 @@ int launch_gemm_nt(const GemmNT& g, bool tile128, hipStream_t s) {
   if (!g.guest && g_cu_guest && g_gemm_polite) {
     GemmNT h = g;
     h.guest = g_cu_guest;
+    h.poll_mask = 3;  // every fourth slab (~5 us): the poll costs the 8-wave kernel 1 % at K = 512 when every slab asks (profiles/r04_skinny_gemm_poll.txt)
     return launch_gemm_nt(h, tile128, s);
   }
   const int ntm = g.m / BT, ntn = g.n / BT;
@@ -739,7 +740,10 @@ int launch_gemm_nt_segs(const GemmNT& g0, const GemmSegs& segs, hipStream_t s, i
   g.A = segs.s[0].A; g.lda = segs.s[0].lda;  // (unused by the kernel in table mode; kept consistent for the tile decode)
   g.B = segs.s[0].B; g.ldb = segs.s[0].ldb;
   g.A2 = g.B2 = nullptr;
-  if (!g.guest && g_cu_guest && g_gemm_polite) g.guest = g_cu_guest;
+  if (!g.guest && g_cu_guest && g_gemm_polite) {
+    g.guest = g_cu_guest;
+    g.poll_mask = 3;
+  }
   const int ntm = g.m / 128, ntn = g.n / 128;
   long nblk;
   if (g.lower) {
